@@ -1,0 +1,174 @@
+/*
+ * vpr_amd.h — C ABI of the MI355X (gfx950) visual-place-recognition + geopose hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (anshium/visual-place-recognition-and-geopose-estimation) is pure Python and has no FFI of
+ * its own; its seam is the nn.Module.forward contract of the validation scripts.  Each entry
+ * point below names the reference interface (file:line, relative to the reference root) whose
+ * device-side arithmetic it replaces.  All pointers are DEVICE pointers unless stated, all
+ * functions are asynchronous on `stream` (a hipStream_t passed as void*), allocate nothing,
+ * keep no global state (safe under hipGraph capture) and never throw: they return a
+ * vpr_status (0 = ok, negative = error).  Workspace is caller-provided; size it with the
+ * matching *_workspace_bytes() call.
+ *
+ * dtype conventions: "bf16" = uint16_t holding the upper 16 bits of an IEEE fp32
+ * (round-to-nearest-even); "f32" = float.
+ */
+#ifndef VPR_AMD_H
+#define VPR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPR_AMD_ABI_VERSION 1
+
+typedef enum vpr_status {
+  VPR_OK = 0,
+  VPR_ERR_INVALID_ARG = -1,   /* null pointer, non-positive dim, unsupported shape */
+  VPR_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels are built for       */
+  VPR_ERR_WORKSPACE = -3,     /* workspace too small                                */
+  VPR_ERR_LAUNCH = -4         /* hipLaunch / hipMemsetAsync reported an error       */
+} vpr_status;
+
+/* Human-readable text for a status code (static storage). */
+const char* vpr_status_string(int status);
+/* ABI version of the loaded library (== VPR_AMD_ABI_VERSION it was built with). */
+int vpr_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * SALAD optimal-transport aggregation.
+ * Replaces: the aggregator inside `feature_extractor(x)` —
+ *   dinov2salad/dinov2salad_validation.py:49-51 (call site), :65 (torch.hub "serizba/salad"),
+ *   output width 8448 pinned at :44.  Algorithm = SURVEY.md §8a-2 (arXiv:2311.15937).
+ *
+ * tokens      [B, tokens_per_image, C] bf16, row-major; row 0 of every image is the cls token,
+ *             rows 1..n are the n patch tokens (DINOv2 layout; n = tokens_per_image-1 = 256).
+ * weights     bf16 [out,in] row-major (nn.Linear / 1x1-conv layout), biases f32:
+ *   w1_sc [2*hidden, C]  rows 0..hidden-1   = score.0.weight,  rows hidden.. = cluster_features.0.weight
+ *   b1_sc [2*hidden]
+ *   w2_s  [m, hidden], b2_s [m]          (score.3)
+ *   w2_c  [l, hidden], b2_c [l]          (cluster_features.3)
+ *   w1_t  [hidden, C], b1_t [hidden]     (token_features.0)
+ *   w2_t  [t, hidden], b2_t [t]          (token_features.2)
+ * dustbin     host float (aggregator.dust_bin)
+ * out_f32     [B, t + l*m] f32 L2-normalised descriptor: [token(t) | V flattened l-major (l*m + m_idx)]
+ * out_bf16    same, rounded to bf16 (may be NULL) — the kNN query/gallery format.
+ * Built for n = 256, m = 64, l = 128, t = 256, hidden = 512, C % 64 == 0, sinkhorn_iters >= 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vpr_salad_weights {
+  const uint16_t* w1_sc; const float* b1_sc;
+  const uint16_t* w2_s;  const float* b2_s;
+  const uint16_t* w2_c;  const float* b2_c;
+  const uint16_t* w1_t;  const float* b1_t;
+  const uint16_t* w2_t;  const float* b2_t;
+} vpr_salad_weights;
+
+size_t vpr_salad_workspace_bytes(int B, int n, int C, int m, int l, int t, int hidden);
+
+int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
+                        const vpr_salad_weights* w, float dustbin,
+                        int m, int l, int t, int hidden, int sinkhorn_iters,
+                        float* out_f32, uint16_t* out_bf16,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Sinkhorn + aggregation stage alone (scores/features already computed) — exposed so tests can
+ * pin it against closed-form known answers.
+ * scores [B, n, m] f32 (token-major), feats [B, n, l] f32, tokfeat [B, t] f32 (un-normalised). */
+int vpr_salad_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
+                                 int B, int n, int m, int l, int t, float dustbin,
+                                 int sinkhorn_iters, float* out_f32, uint16_t* out_bf16,
+                                 void* stream);
+
+/* Generic C[M,N] = act(A[M,K] * W[N,K]^T + bias) on MFMA (bf16 in, f32 accumulate).
+ * The SALAD MLPs are built from it; exposed for parity tests of the dense stage.
+ * A row r lives at A + (r / a_group_rows) * a_group_stride + (r % a_group_rows) * lda (elements);
+ * pass a_group_rows = 0 for a plain lda matrix.  out_is_bf16 selects the C element type.
+ * Requires K % 64 == 0. */
+int vpr_gemm_nt_bf16(const uint16_t* A, int lda, int a_group_rows, long long a_group_stride,
+                     const uint16_t* W, int ldw, const float* bias, int relu,
+                     void* C, int ldc, int out_is_bf16, int M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * kNN: cosine top-k of L2-normalised descriptors against a gallery shard.
+ * Replaces: nothing in the reference tree (north-star addition between the
+ * SALAD descriptor, dinov2salad_validation.py:51, and the post-processing at :84).
+ *
+ * q        [B, D] bf16, gallery [N, D] bf16 (row-major, D % 64 == 0)
+ * out_val  [B, k] f32 scores, descending; out_idx [B, k] int32 = index_base + local row.
+ * Ordering contract: key = (score desc, index asc) where score = fp32 rounding of the exact
+ * (fp64-accumulated) dot product of the bf16 operands — independent of tile order, so shards
+ * merged with vpr_topk_merge give the same answer as one unsharded call.
+ * If N < k the tail is filled with (-inf, -1).   1 <= k <= 64.
+ * ------------------------------------------------------------------------------------------ */
+size_t vpr_knn_workspace_bytes(int B, int N, int D, int k);
+
+int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                 int index_base, float* out_val, int32_t* out_idx,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Stage entry points of vpr_knn_topk (same workspace layout), so the dominant kernel can be
+ * timed by itself (bench.py roofline) and tested by itself.
+ *   scores:  S[b, n] = <q_b, g_n>  (bf16 MFMA, f32 accumulate)  -> workspace
+ *   select:  per-query candidate selection + exact rescoring + final ordering           */
+int vpr_knn_scores(const uint16_t* q, const uint16_t* gallery, int B, int N, int D,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                   int index_base, float* out_val, int32_t* out_idx,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Device pointer + leading dimension of the score matrix inside a workspace (for tests). */
+float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k, int* ld_out);
+
+/* Merge per-shard top-k lists (after an all-gather): vals/idxs [shards, B, k] -> [B, k],
+ * same ordering contract.  Entries with idx < 0 are padding. */
+int vpr_topk_merge(const float* vals, const int32_t* idxs, int shards, int B, int k,
+                   float* out_val, int32_t* out_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pose head: out = W2 * relu(W1 * x + b1) + b2   (f32 end to end, f32-input MFMA),
+ * optionally followed by F.normalize(p=2, eps=1e-6) of the output pair
+ * [sincos_offset, sincos_offset+1].
+ * Replaces: DINOv2RegressionModel.regressor  dinov2salad/dinov2salad_validation.py:43-47,52
+ *           Swin-Base MLP head              swin_transformer/val_and_test_swin_2.py:168-177
+ *           sin/cos heads  angle_prediction/swin/swin_angle_finetuning_sin_cos.py:56-62,
+ *                          angle_prediction/swin/swin_angle_finetuning_gemini.py:101-106
+ * With hidden = 0 the head is the single Linear(D, n_out): out = W2 * x + b2 (W1,b1 ignored)
+ *           swin_transformer/swin_validation.py:41,46.
+ * x [B, D] f32; W1 [hidden, D]; b1 [hidden]; W2 [n_out, hidden or D]; b2 [n_out]; out [B, n_out].
+ * A fused (lat, lon, sin, cos) head is n_out = 4 with row-concatenated W2 (block structure is
+ * the caller's business) and sincos_offset = 2.  sincos_offset < 0 disables the normalise.
+ * Requires D % 16 == 0, hidden % 32 == 0 (or 0), 1 <= n_out <= 8.
+ * ------------------------------------------------------------------------------------------ */
+size_t vpr_pose_head_workspace_bytes(int B, int D, int hidden, int n_out);
+
+int vpr_pose_head(const float* x, const float* W1, const float* b1,
+                  const float* W2, const float* b2, float* out,
+                  int B, int D, int hidden, int n_out, int sincos_offset,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh
+ * Replaces: `outputs.pooler_output` + `self.regressor`  swin_transformer/swin_validation.py:43-46
+ *           (HF SwinModel: layernorm -> AdaptiveAvgPool1d(1) over tokens) and the normalised
+ *           sin/cos variant angle_prediction/swin/swin_angle_finetuning_sin_cos.py:58-62.
+ * x [B, T, H] (bf16 if x_is_bf16 else f32); gamma, beta [H] f32; eps as in the model config.
+ * pooled_out [B, H] f32 (may be NULL); Wh [n_out, H], bh [n_out], out [B, n_out] (Wh may be
+ * NULL to skip the head, e.g. when an MLP head follows through vpr_pose_head).
+ * H in {512, 768, 1024, 1536}; 0 <= n_out <= 8.
+ * ------------------------------------------------------------------------------------------ */
+int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, int H,
+                         const float* gamma, const float* beta, float eps,
+                         float* pooled_out,
+                         const float* Wh, const float* bh, int n_out, int sincos_offset,
+                         float* out, void* stream);
+
+/* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
+int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPR_AMD_H */

@@ -1,0 +1,41 @@
+"""MFMA GEMM (vpr_gemm_nt_bf16) against an fp64 reference on identical bf16 operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K,relu,out_bf16", [
+    (128, 128, 64, False, False),
+    (256, 64, 128, True, False),
+    (300, 200, 192, True, True),      # ragged M, N
+    (64, 512, 1024, True, True),      # token MLP layer 1 shape
+    (1024, 1024, 1024, True, True),   # fused score+cluster layer 1 (4 images)
+    (1024, 64, 512, False, False),    # score layer 2
+    (1024, 128, 512, False, False),   # cluster layer 2
+    (5, 3, 64, False, False),
+])
+def test_gemm_nt(dev, M, N, K, relu, out_bf16):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    # asymmetric, non-constant bias catches row/col swaps
+    bias = torch.linspace(-1, 1, N)
+    ref = a.double() @ w.double().T + bias.double()
+    if relu:
+        ref = torch.relu(ref)
+    out = ops.gemm_nt_bf16(a.to(dev), w.to(dev), bias.to(dev), relu,
+                           torch.bfloat16 if out_bf16 else torch.float32).cpu().double()
+    tol = 2e-2 if out_bf16 else 1e-4          # bf16 output: half an ulp of the largest values
+    assert (out - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I (padded) with an asymmetric W: catches a transposed C write (cdna guide §3)."""
+    from vpr_amd import ops
+    K = 64
+    a = torch.eye(K).to(torch.bfloat16)
+    w = (torch.arange(48 * K).reshape(48, K) % 251).float().to(torch.bfloat16)
+    out = ops.gemm_nt_bf16(a.to(dev), w.to(dev)).cpu()
+    assert torch.equal(out, w.float().T)

@@ -1,0 +1,88 @@
+"""GPU parity of the regression / angle heads against oracle/heads.py (fp64) — outputs within
+1e-4 (north star tolerance on the standardised head output; observed ~1e-6)."""
+import pytest
+import torch
+
+from oracle import heads as oheads
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _linear_init(out_f, in_f, g):
+    bound = 1.0 / in_f ** 0.5
+    return ((torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound, (torch.rand(out_f, generator=g) * 2 - 1) * bound)
+
+
+@pytest.mark.parametrize("B,D,hidden,n_out,off", [
+    (64, 8448, 512, 2, -1),     # DINOv2RegressionModel.regressor
+    (64, 8448, 512, 4, 2),      # fused (lat, lon, sin, cos)
+    (256, 1024, 512, 2, -1),    # Swin-Base MLP head
+    (7, 768, 384, 2, 0),        # sin/cos MLP head, ragged batch
+    (1, 64, 32, 1, -1),
+])
+def test_mlp_head(dev, B, D, hidden, n_out, off):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(B + D)
+    x = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1) if D == 8448 else torch.randn(B, D, generator=g)
+    W1, b1 = _linear_init(hidden, D, g)
+    W2, b2 = _linear_init(n_out, hidden, g)
+    ref = oheads.mlp_head(x, W1, b1, W2, b2, off)
+    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), off).cpu().double()
+    err = (out - ref).abs().max().item()
+    print("mlp head err", err)
+    assert err < TOL
+
+
+@pytest.mark.parametrize("B,D,n_out,off", [(8, 768, 2, -1), (8, 768, 2, 0), (33, 1024, 4, 2)])
+def test_linear_head(dev, B, D, n_out, off):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(D + n_out)
+    x = torch.randn(B, D, generator=g)
+    W2, b2 = _linear_init(n_out, D, g)
+    ref = oheads.mlp_head(x, None, None, W2, b2, off)
+    out = ops.pose_head(x.to(dev), None, None, W2.to(dev), b2.to(dev), off).cpu().double()
+    assert (out - ref).abs().max().item() < TOL
+
+
+def test_head_is_deterministic(dev):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 8448, generator=g).to(dev)
+    W1, b1 = _linear_init(512, 8448, g)
+    W2, b2 = _linear_init(4, 512, g)
+    args = [t.to(dev) for t in (W1, b1, W2, b2)]
+    a = ops.pose_head(x, *args, 2)
+    b = ops.pose_head(x, *args, 2)
+    assert torch.equal(a, b)
+
+
+def test_zero_pair_normalise_eps(dev):
+    """F.normalize eps path: a zero (sin, cos) pair stays zero instead of NaN."""
+    from vpr_amd import ops
+    x = torch.zeros(2, 64)
+    W2, b2 = torch.zeros(2, 64), torch.zeros(2)
+    out = ops.pose_head(x.to(dev), None, None, W2.to(dev), b2.to(dev), 0).cpu()
+    assert torch.equal(out, torch.zeros(2, 2))
+
+
+@pytest.mark.parametrize("B,T,H,dtype", [
+    (8, 49, 768, torch.float32),      # Swin-T
+    (4, 144, 1024, torch.bfloat16),   # Swin-B 384
+    (256, 49, 1024, torch.bfloat16),  # BASELINE config 4
+    (3, 5, 512, torch.float32),
+    (2, 1, 1536, torch.bfloat16),
+])
+def test_ln_meanpool_head(dev, B, T, H, dtype):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(T + H)
+    x = (torch.randn(B, T, H, generator=g) * 1.5 + 0.3).to(dtype)
+    gamma = 1 + 0.1 * torch.randn(H, generator=g)
+    beta = 0.1 * torch.randn(H, generator=g)
+    Wh, bh = _linear_init(4, H, g)
+    pooled_ref, out_ref = oheads.ln_meanpool_head(x, gamma, beta, 1e-5, Wh, bh, 2)
+    pooled, out = ops.ln_meanpool_head(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, Wh.to(dev), bh.to(dev), 2)
+    assert (pooled.cpu().double() - pooled_ref).abs().max().item() < 2e-5
+    assert (out.cpu().double() - out_ref).abs().max().item() < TOL
+    pooled_only, none = ops.ln_meanpool_head(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
+    assert none is None and torch.equal(pooled_only, pooled)

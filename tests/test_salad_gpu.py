@@ -1,0 +1,121 @@
+"""GPU parity of the SALAD stage against oracle/salad.py and closed-form known answers
+(SURVEY.md §8c (1)-(5)).  Floating point: descriptor entries within 1e-4 absolute (north star),
+observed error is printed by the helper."""
+import math
+
+import pytest
+import torch
+
+from oracle import salad as osalad
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _weights(C, seed, hidden=512, m=64, l=128, t=256, std=0.02):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g) * std
+    w = dict(w1_sc=r(2 * hidden, C), b1_sc=r(2 * hidden), w2_s=r(m, hidden), b2_s=r(m),
+             w2_c=r(l, hidden), b2_c=r(l), w1_t=r(hidden, C), b1_t=r(hidden),
+             w2_t=r(t, hidden), b2_t=r(t))
+    for k in list(w):
+        if k.startswith("w"):
+            w[k] = w[k].to(torch.bfloat16)
+    return w
+
+
+def _to_dev(w, dev, dustbin):
+    from vpr_amd.ops import SaladWeights
+    return SaladWeights(**{k: v.to(dev) for k, v in w.items()}, dustbin=dustbin)
+
+
+def test_sinkhorn_stage_matches_oracle(dev):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B = 5
+    scores = torch.randn(B, 256, 64, generator=g) * 2.0
+    feats = torch.randn(B, 256, 128, generator=g)
+    tok = torch.randn(B, 256, generator=g)
+    ref = osalad.sinkhorn_aggregate(scores, feats, tok, 1.0, 3)
+    out, out16 = ops.salad_sinkhorn_aggregate(scores.to(dev), feats.to(dev), tok.to(dev), 1.0, 3, want_bf16=True)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print("sinkhorn stage max abs err", err)
+    assert err < 2e-6
+    assert torch.equal(out16.cpu(), out.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("iters", [1, 3, 7])
+def test_sinkhorn_iteration_count(dev, iters):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(iters)
+    scores = torch.randn(2, 256, 64, generator=g)
+    feats = torch.randn(2, 256, 128, generator=g)
+    tok = torch.randn(2, 256, generator=g)
+    ref = osalad.sinkhorn_aggregate(scores, feats, tok, 0.5, iters)
+    out, _ = ops.salad_sinkhorn_aggregate(scores.to(dev), feats.to(dev), tok.to(dev), 0.5, iters)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-6
+
+
+def test_uniform_scores_closed_form(dev):
+    """Known answer (2): all scores == dustbin -> P = 1/n for every cluster, so every cluster
+    vector is normalize(mean_j F[:, j]) and all m cluster columns are identical."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(1, 256, 128, generator=g)
+    tok = torch.randn(1, 256, generator=g)
+    scores = torch.full((1, 256, 64), 1.0)
+    out, _ = ops.salad_sinkhorn_aggregate(scores.to(dev), feats.to(dev), tok.to(dev), 1.0, 3)
+    out = out.cpu().double()[0]
+    V = out[256:].reshape(128, 64)
+    mean_dir = torch.nn.functional.normalize(feats[0].double().mean(0), dim=0) / math.sqrt(65.0)
+    assert (V - mean_dir[:, None]).abs().max().item() < 1e-6
+    t_ref = torch.nn.functional.normalize(tok[0].double(), dim=0) / math.sqrt(65.0)
+    assert (out[:256] - t_ref).abs().max().item() < 1e-6
+
+
+def test_norm_shares_and_invariances(dev):
+    """Known answers (3)-(5): squared-norm shares 1/65 | 64/65, token-permutation invariance,
+    score-shift invariance (scores and dustbin shifted together)."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(1, 256, 64, generator=g)
+    feats = torch.randn(1, 256, 128, generator=g)
+    tok = torch.randn(1, 256, generator=g)
+    run = lambda s, f, d: ops.salad_sinkhorn_aggregate(s.to(dev), f.to(dev), tok.to(dev), d, 3)[0].cpu().double()[0]
+    out = run(scores, feats, 1.0)
+    assert abs(out.pow(2).sum().item() - 1.0) < 1e-6
+    assert abs(out[:256].pow(2).sum().item() - 1.0 / 65.0) < 1e-6
+    per_cluster = out[256:].reshape(128, 64).pow(2).sum(0)
+    assert (per_cluster - 1.0 / 65.0).abs().max().item() < 1e-6
+    perm = torch.randperm(256, generator=g)
+    out_p = run(scores[:, perm], feats[:, perm], 1.0)
+    assert (out_p - out).abs().max().item() < 1e-6
+    out_s = run(scores + 3.25, feats, 1.0 + 3.25)
+    assert (out_s - out).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("C,B", [(768, 3), (1024, 4)])
+def test_salad_end_to_end_matches_oracle(dev, C, B):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(C + B)
+    tokens = torch.randn(B, 257, C, generator=g).to(torch.bfloat16)
+    w = _weights(C, seed=C)
+    ref = osalad.salad_aggregate(tokens, w, dustbin=1.0, iters=3)
+    out, out16 = ops.salad_aggregate(tokens.to(dev), _to_dev(w, dev, 1.0), 3)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"SALAD C={C} max abs err {err:.3e} (entries ~{ref.abs().mean().item():.3e})")
+    assert err < TOL
+    assert torch.equal(out16.cpu(), out.cpu().to(torch.bfloat16))
+    assert (out.cpu().double().pow(2).sum(1) - 1).abs().max().item() < 1e-5
+
+
+def test_salad_larger_scores(dev):
+    """Weights with a wide score range exercise the max-subtraction in both LSE passes."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    tokens = (torch.randn(2, 257, 768, generator=g) * 2).to(torch.bfloat16)
+    w = _weights(768, seed=10, std=0.08)
+    ref = osalad.salad_aggregate(tokens, w, dustbin=-2.0, iters=3)
+    out, _ = ops.salad_aggregate(tokens.to(dev), _to_dev(w, dev, -2.0), 3)
+    assert torch.isfinite(out).all()
+    assert (out.cpu().double() - ref).abs().max().item() < TOL

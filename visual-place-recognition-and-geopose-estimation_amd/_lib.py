@@ -1,0 +1,81 @@
+"""ctypes binding of libvpr_amd.so — one prototype per entry point of include/vpr_amd.h.
+
+There is no fallback: if the library is missing, `lib()` raises with the build command.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ABI_VERSION = 1
+
+STATUS_OK = 0
+
+
+class SaladWeightsC(Structure):
+    """struct vpr_salad_weights (device pointers)."""
+    _fields_ = [(n, c_void_p) for n in
+                ("w1_sc", "b1_sc", "w2_s", "b2_s", "w2_c", "b2_c", "w1_t", "b1_t", "w2_t", "b2_t")]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol is exported
+PROTOTYPES = {
+    "vpr_status_string": (c_char_p, [c_int]),
+    "vpr_abi_version": (c_int, []),
+    "vpr_salad_workspace_bytes": (c_size_t, [c_int] * 7),
+    "vpr_salad_aggregate": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(SaladWeightsC), c_float,
+                                    c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "vpr_salad_sinkhorn_aggregate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "vpr_gemm_nt_bf16": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p, c_int,
+                                 c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vpr_knn_workspace_bytes": (c_size_t, [c_int] * 4),
+    "vpr_knn_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_scores_ptr": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "vpr_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vpr_pose_head_workspace_bytes": (c_size_t, [c_int] * 4),
+    "vpr_pose_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "vpr_ln_meanpool_head": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vpr_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+}
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libvpr_amd.so")
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension is required (there is no CPU fallback). "
+                "Build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "or `make -C visual-place-recognition-and-geopose-estimation_amd/csrc`.")
+        handle = ctypes.CDLL(path)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(handle, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.vpr_abi_version() != ABI_VERSION:
+            raise RuntimeError("libvpr_amd.so ABI version mismatch; rebuild the library")
+        _LIB = handle
+    return _LIB
+
+
+def check(status: int, what: str) -> None:
+    if status != STATUS_OK:
+        msg = lib().vpr_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (status {status})")

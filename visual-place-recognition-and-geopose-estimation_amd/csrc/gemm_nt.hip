@@ -1,0 +1,157 @@
+// gemm_nt.hip — C[M,N] = act(A[M,K] * W[N,K]^T + bias), bf16 operands, f32 accumulate (MFMA).
+//
+// Used for the SALAD token MLPs (score / cluster_features / token_features
+// 1x1-conv + Linear layers of the aggregator called at
+// dinov2salad/dinov2salad_validation.py:49-51).  MFMA-bound stage of the hot path.
+//
+// Structure (cdna guide §5, "minimum 2-phase"): 128 x BN output tile per 256-thread workgroup,
+// BK = 64, both operand tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a 2-deep LDS
+// ring with the XOR swizzle of vpr_common.cuh on the source address, fragments read with
+// ds_read_b128, v_mfma_f32_32x32x16_bf16, one barrier per K-step.  Workgroup ids are remapped
+// so that the workgroups of one XCD (blockIdx % 8) own a contiguous run of tiles and re-use the
+// same A panel out of that XCD's L2.
+#include "vpr_common.cuh"
+#include "vpr_internal.h"
+
+namespace vpr {
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+    const uint16_t* __restrict__ A, int lda, int a_group_rows, long long a_group_stride,
+    const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int relu,
+    void* __restrict__ Cout, int ldc, int out_is_bf16, int M, int N, int K,
+    int tiles_m, int tiles_n) {
+  constexpr int BM = 128;
+  constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
+  constexpr int TN = BN / WN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * TILE_ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware bijective remap (cdna guide §5 "XCD swizzle must be bijective").
+  const int nwg = tiles_m * tiles_n;
+  int tile;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // Per-lane source row pointers for the staging groups this wave owns (group g = 8 tile rows;
+  // wave w stages groups w, w+4, ...).
+  constexpr int AG = BM / 8 / 4;  // A groups per wave
+  constexpr int BG = BN / 8 / 4;  // W groups per wave
+  const uint16_t* a_src[AG];
+  const uint16_t* w_src[BG];
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    int r = m0 + (wave + 4 * i) * 8 + (lane >> 3);
+    r = r < M ? r : M - 1;
+    const uint16_t* p = a_group_rows > 0
+        ? A + (long long)(r / a_group_rows) * a_group_stride + (long long)(r % a_group_rows) * lda
+        : A + (long long)r * lda;
+    const int tr = (wave + 4 * i) * 8 + (lane >> 3);
+    a_src[i] = p + (((lane & 7) ^ ((tr >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < BG; ++i) {
+    int r = n0 + (wave + 4 * i) * 8 + (lane >> 3);
+    r = r < N ? r : N - 1;
+    const int tr = (wave + 4 * i) * 8 + (lane >> 3);
+    w_src[i] = W + (long long)r * ldw + (((lane & 7) ^ ((tr >> 1) & 7)) << 3);
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = K >> 6;
+  auto stage = [&](int buf, int ks) {
+    char* ta = smem + buf * STAGE_BYTES;
+    char* tw = ta + BM * TILE_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) glds16(a_src[i] + ks * 64, ta + (wave + 4 * i) * 8 * TILE_ROW_BYTES);
+#pragma unroll
+    for (int i = 0; i < BG; ++i) glds16(w_src[i] + ks * 64, tw + (wave + 4 * i) * 8 * TILE_ROW_BYTES);
+  };
+
+  stage(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    // Own LDS-DMA drained, then the barrier: stage ks has landed for every wave and every wave
+    // is done reading buffer (ks+1)&1.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+    const char* ta = smem + (ks & 1) * STAGE_BYTES;
+    const char* tw = ta + BM * TILE_ROW_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[TM], bfr[TN];
+      const int chunk = (lane >> 5) + 2 * s;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = lds_frag(ta, (wm * TM + i) * 32 + (lane & 31), chunk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = lds_frag(tw, (wn * TN + j) * 32 + (lane & 31), chunk);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // Epilogue.  C/D map of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][e] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (m < M && n < N) {
+          if (out_is_bf16)
+            reinterpret_cast<uint16_t*>(Cout)[(long long)m * ldc + n] = f32_to_bf16_bits(v);
+          else
+            reinterpret_cast<float*>(Cout)[(long long)m * ldc + n] = v;
+        }
+      }
+    }
+}
+
+int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_group_stride,
+                   const uint16_t* W, int ldw, const float* bias, int relu, void* C, int ldc,
+                   int out_is_bf16, int M, int N, int K, hipStream_t stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VPR_ERR_INVALID_ARG;
+  if (K % 64 != 0 || lda < K || ldw < K || ldc < N) return VPR_ERR_UNSUPPORTED;
+  if ((lda % 8) || (ldw % 8) || (a_group_rows > 0 && (a_group_stride % 8))) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return VPR_ERR_UNSUPPORTED;
+  const int tiles_m = (M + 127) / 128;
+  if (N > 64) {
+    const int tiles_n = (N + 127) / 128;
+    constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
+                       A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
+                       M, N, K, tiles_m, tiles_n);
+  } else {
+    const int tiles_n = 1;
+    constexpr size_t lds = 2 * (128 + 64) * TILE_ROW_BYTES;
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 4, 1>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
+                       A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
+                       M, N, K, tiles_m, tiles_n);
+  }
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+
+}  // namespace vpr

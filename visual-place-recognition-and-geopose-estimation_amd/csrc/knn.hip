@@ -1,0 +1,477 @@
+// knn.hip — cosine top-k of bf16 descriptors against a gallery shard.
+//
+// The reference has no retrieval code; this is the north-star stage that sits between the
+// SALAD descriptor (dinov2salad/dinov2salad_validation.py:51) and post-processing (:84).
+//
+// Pipeline (all on one stream, no host sync):
+//   1. knn_scores_kernel   S[b,n] = <q_b, g_n>   — HBM-bound stream of the gallery, MFMA
+//                          (v_mfma_f32_16x16x32_bf16) used only because a 64-query tile needs
+//                          64 FLOP per gallery byte.  THE dominant kernel (roofline: HBM).
+//   2. select_kernel       per (query, 4096-score chunk): top-KP candidates by the MFMA score
+//                          (KP = oversampled k), iterated until <= 4096 candidates remain.
+//   3. final_kernel        per query: top-KP of the candidates, EXACT rescoring of those KP rows
+//                          (bf16 products accumulated in f64, fixed order), final ordering by
+//                          (f32(score) desc, index asc), write top-k.
+// The exact rescoring makes the result independent of MFMA accumulation order: indices are
+// bit-exact against oracle/knn.py as long as the true top-k lie inside the approximate top-KP
+// (MFMA f32 error ~1e-6 vs. the k-th..KP-th score gap).
+#include <math.h>
+#include "vpr_common.cuh"
+#include "vpr_internal.h"
+
+namespace vpr {
+
+constexpr int KNN_TR = 144;        // gallery rows per tile (9 MFMA column blocks of 16)
+constexpr int KNN_QT = 64;         // queries per tile (4 waves x 16)
+constexpr int KNN_CHUNK = 4096;    // scores per select workgroup
+constexpr int KNN_WG_PER_CU = 3;
+
+__host__ __device__ inline int knn_kp(int k) {
+  int kp = 2 * k > k + 8 ? 2 * k : k + 8;
+  return (kp + 7) / 8 * 8;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. score kernel.  Workgroup w owns gallery rows [N*w/nwg, N*(w+1)/nwg) — a balanced static
+// partition over a grid that is fully resident (nwg <= CUs * KNN_WG_PER_CU), so every workgroup
+// streams the same number of HBM bytes and they finish together; its rows are cut into equal
+// tiles of <= KNN_TR rows.  Per tile and K-step (64 of D): the gallery tile [th x 64] (HBM) and
+// the query tile [64 x 64] (L2) land in LDS by LDS-DMA, 2-deep ring, one barrier per K-step.
+// Wave w multiplies queries 16w..16w+15 (MFMA A operand) with every 16-row gallery block
+// (B operand): C[q][n], lane = gallery row n -> coalesced 64-B score stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
+    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G, float* __restrict__ S,
+    int B, int N, int D, int ldS) {
+  constexpr int NB = KNN_TR / 16;
+  constexpr int GG = KNN_TR / 8;            // gallery staging groups (8 rows each)
+  constexpr int NGRP = GG + KNN_QT / 8;     // + query staging groups
+  constexpr int GPW = (NGRP + 3) / 4;       // groups per wave (upper bound)
+  constexpr int STAGE_BYTES = (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  const int qb = blockIdx.y;
+  const long long r_begin = (long long)N * blockIdx.x / nwg;
+  const long long r_end = (long long)N * (blockIdx.x + 1) / nwg;
+  const int len = (int)(r_end - r_begin);
+  if (len <= 0) return;
+  const int ntile = (len + KNN_TR - 1) / KNN_TR;
+  const int th_nom = (len + ntile - 1) / ntile;
+  const int nk = D >> 6;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int row0 = (int)r_begin + t * th_nom;
+    const int th = min(th_nom, (int)r_end - row0);   // valid rows of this tile (>= 1)
+
+    // Source row pointers of the staging groups this wave owns.
+    const uint16_t* src[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+      const int g = wave + 4 * i;
+      const int tr = (g < GG ? g : g - GG) * 8 + (lane >> 3);   // row inside its tile
+      const int sw = ((lane & 7) ^ ((tr >> 1) & 7)) << 3;
+      if (g < GG) {
+        const int r = row0 + min(tr, th - 1);
+        src[i] = G + (long long)r * D + sw;
+      } else {
+        const int r = min(qb * KNN_QT + tr, B - 1);
+        src[i] = Q + (long long)r * D + sw;
+      }
+    }
+    const int gvalid = (th + 7) >> 3;   // gallery groups that hold at least one valid row
+
+    auto stage = [&](int buf, int ks) {
+      char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < GPW; ++i) {
+        const int g = wave + 4 * i;
+        if (g < GG) {
+          if (g < gvalid) glds16(src[i] + ks * 64, base + g * 8 * TILE_ROW_BYTES);
+        } else if (g < NGRP) {
+          glds16(src[i] + ks * 64, base + KNN_TR * TILE_ROW_BYTES + (g - GG) * 8 * TILE_ROW_BYTES);
+        }
+      }
+    };
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();   // previous tile's last compute is done before its buffers are refilled
+    stage(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+      const char* tg = smem + (ks & 1) * STAGE_BYTES;
+      const char* tq = tg + KNN_TR * TILE_ROW_BYTES;
+      const bf16x8 a0 = lds_frag(tq, 16 * wave + (lane & 15), (lane >> 4));
+      const bf16x8 a1 = lds_frag(tq, 16 * wave + (lane & 15), 4 + (lane >> 4));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (nb * 16 < th) {
+          const bf16x8 b0 = lds_frag(tg, 16 * nb + (lane & 15), (lane >> 4));
+          const bf16x8 b1 = lds_frag(tg, 16 * nb + (lane & 15), 4 + (lane >> 4));
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+
+    // C/D map of 16x16: col (gallery row) = lane&15, row (query) = 4*(lane>>4) + e.
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = 16 * nb + (lane & 15);
+      if (n < th) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e;
+          if (q < B) S[(long long)q * ldS + row0 + n] = acc[nb][e];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-wide iterative top-KP over <= 4096 (value, index) pairs held 16 per thread.
+// Key order: value desc, index asc (packed into one u64 so a max-reduction does both).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t o) {
+  const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long make_key(float v, int idx) {
+  // idx >= 0 real entry; idx < 0 padding (sorts last among equal values, and carries -inf).
+  return ((unsigned long long)f32_orderable(v) << 32) | (uint32_t)(0x7fffffff - idx);
+}
+__device__ __forceinline__ int key_idx(unsigned long long k) { return 0x7fffffff - (int)(uint32_t)k; }
+__device__ __forceinline__ float key_val(unsigned long long k) { return f32_from_orderable((uint32_t)(k >> 32)); }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(v, o, 64);
+    v = other > v ? other : v;
+  }
+  return v;
+}
+
+constexpr unsigned long long KEY_DEAD = 0ull;   // below every real key (orderable(-inf) > 0)
+
+// keys[16] per thread; emits the kp largest keys in descending order into out_keys (LDS or
+// global, visible to the whole block after the call).  `red` is 4 u64 of LDS scratch.
+template <typename OutPtr>
+__device__ __forceinline__ void block_topk(unsigned long long (&keys)[16], int kp,
+                                           unsigned long long* red, OutPtr out_keys) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long best = KEY_DEAD;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) best = keys[i] > best ? keys[i] : best;
+#pragma unroll 1
+  for (int r = 0; r < kp; ++r) {
+    const unsigned long long wbest = wave_max_u64(best);
+    if (lane == 0) red[wave] = wbest;
+    __syncthreads();
+    unsigned long long top = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) top = red[w] > top ? red[w] : top;
+    __syncthreads();
+    if (threadIdx.x == 0) out_keys[r] = top;
+    if (best == top && top != KEY_DEAD) {   // keys are unique (index is part of the key)
+      best = KEY_DEAD;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (keys[i] == top) keys[i] = KEY_DEAD;
+        best = keys[i] > best ? keys[i] : best;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Branch-free load of up to 16 (value, index) pairs per thread: out-of-range positions are
+// clamped for the load and turned into KEY_DEAD by a select (keeps the 16 keys in registers).
+__device__ __forceinline__ void load_keys(unsigned long long (&keys)[16], const float* __restrict__ v,
+                                          const int32_t* __restrict__ ix, int L, int base) {
+  if (ix != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = base + i * 256 + (int)threadIdx.x;
+      const int pc = p < L ? p : L - 1;
+      const int id = ix[pc];
+      const float val = v[pc];
+      keys[i] = (p < L && id >= 0) ? make_key(val, id) : KEY_DEAD;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = base + i * 256 + (int)threadIdx.x;
+      const int pc = p < L ? p : L - 1;
+      const float val = v[pc];
+      keys[i] = p < L ? make_key(val, p) : KEY_DEAD;
+    }
+  }
+}
+
+// 2. select: grid (chunks, B).  in_idx == nullptr -> index = position (+0); else explicit.
+__global__ __launch_bounds__(256) void knn_select_kernel(
+    const float* __restrict__ in_val, const int32_t* __restrict__ in_idx, int L, long long ld_in,
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk) {
+  __shared__ unsigned long long red[4];
+  __shared__ unsigned long long outk[128];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* v = in_val + (long long)b * ld_in;
+  const int32_t* ix = in_idx ? in_idx + (long long)b * ld_in : nullptr;
+  unsigned long long keys[16];
+  load_keys(keys, v, ix, L, c * KNN_CHUNK);
+  block_topk(keys, kp, red, outk);
+  if ((int)threadIdx.x < kp) {
+    const unsigned long long k = outk[threadIdx.x];
+    const long long o = ((long long)b * nchunk + c) * kp + threadIdx.x;
+    out_val[o] = k == KEY_DEAD ? -INFINITY : key_val(k);
+    out_idx[o] = k == KEY_DEAD ? -1 : key_idx(k);
+  }
+}
+
+// 3. final: grid (B).  Candidates (<= 4096) -> top-KP -> exact f64 rescoring -> order -> top-k.
+__global__ __launch_bounds__(256) void knn_final_kernel(
+    const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, int L, long long ld_in,
+    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G, int D, int k, int kp,
+    int index_base, float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ unsigned long long red[4];
+  __shared__ unsigned long long outk[128];
+  __shared__ float exact[128];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* v = cand_val + (long long)b * ld_in;
+  const int32_t* ix = cand_idx ? cand_idx + (long long)b * ld_in : nullptr;
+  unsigned long long keys[16];
+  load_keys(keys, v, ix, L, 0);
+  block_topk(keys, kp, red, outk);
+
+  // Exact rescoring: wave w takes candidates w, w+4, ...; lane strides over 16-B chunks of the
+  // two rows; bf16*bf16 is exact in f64 and the f64 sum order is fixed (lane-strided, then a
+  // butterfly), so the result does not depend on how the candidate was found.
+  const uint16_t* qrow = Q + (long long)b * D;
+  const int nchunks = D >> 3;
+  for (int c = wave; c < kp; c += 4) {
+    const unsigned long long key = outk[c];
+    float s = -INFINITY;
+    if (key != KEY_DEAD) {
+      const uint16_t* grow = G + (long long)key_idx(key) * D;
+      double accd = 0.0;
+      for (int ch = lane; ch < nchunks; ch += 64) {
+        const s16x8 qa = *reinterpret_cast<const s16x8*>(qrow + ch * 8);
+        const s16x8 ga = *reinterpret_cast<const s16x8*>(grow + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          accd = fma((double)bf16_bits_to_f32((uint16_t)qa[j]), (double)bf16_bits_to_f32((uint16_t)ga[j]), accd);
+      }
+      accd = wave_sum_f64(accd);
+      s = (float)accd;
+    }
+    if (lane == 0) exact[c] = s;
+  }
+  __syncthreads();
+
+  // Final ordering by (exact f32 score desc, index asc): rank by counting.
+  if ((int)threadIdx.x < kp) {
+    const int i = threadIdx.x;
+    const unsigned long long ki = outk[i];
+    int rank;
+    if (ki == KEY_DEAD) {
+      // padding entries keep their (stable) position behind every real entry
+      rank = i;
+    } else {
+      const unsigned long long mine = make_key(exact[i], key_idx(ki));
+      rank = 0;
+      for (int j = 0; j < kp; ++j) {
+        const unsigned long long kj = outk[j];
+        if (kj == KEY_DEAD) continue;
+        const unsigned long long other = make_key(exact[j], key_idx(kj));
+        rank += other > mine ? 1 : 0;
+      }
+    }
+    if (rank < k) {
+      out_val[(long long)b * k + rank] = ki == KEY_DEAD ? -INFINITY : exact[i];
+      out_idx[(long long)b * k + rank] = ki == KEY_DEAD ? -1 : key_idx(ki) + index_base;
+    }
+  }
+}
+
+// Merge of per-shard lists: vals/idxs [shards, B, k] -> [B, k].  shards*k <= 4096.
+__global__ __launch_bounds__(256) void topk_merge_kernel(
+    const float* __restrict__ vals, const int32_t* __restrict__ idxs, int shards, int B, int k,
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ unsigned long long red[4];
+  __shared__ unsigned long long outk[128];
+  const int b = blockIdx.x;
+  const int L = shards * k;
+  unsigned long long keys[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = i * 256 + (int)threadIdx.x;
+    const int pc = p < L ? p : L - 1;
+    const int s = pc / k, j = pc % k;
+    const long long o = ((long long)s * B + b) * k + j;
+    const int id = idxs[o];
+    const float val = vals[o];
+    keys[i] = (p < L && id >= 0) ? make_key(val, id) : KEY_DEAD;
+  }
+  block_topk(keys, k, red, outk);
+  if ((int)threadIdx.x < k) {
+    const unsigned long long key = outk[threadIdx.x];
+    out_val[(long long)b * k + threadIdx.x] = key == KEY_DEAD ? -INFINITY : key_val(key);
+    out_idx[(long long)b * k + threadIdx.x] = key == KEY_DEAD ? -1 : key_idx(key);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct KnnPlan {
+  int Bpad, ldS, kp;
+  int nlevel;            // number of select levels before the final kernel
+  int L[4], nchunk[4];   // input length / chunk count per level
+  size_t off_S, off_cv[2], off_ci[2], total;
+};
+
+static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0 || k > 64 || (D % 64) != 0) return false;
+  p->Bpad = (B + KNN_QT - 1) / KNN_QT * KNN_QT;
+  p->ldS = (N + 63) / 64 * 64;
+  p->kp = knn_kp(k);
+  p->nlevel = 0;
+  int L = N;
+  while (L > KNN_CHUNK) {
+    if (p->nlevel >= 4) return false;
+    p->L[p->nlevel] = L;
+    p->nchunk[p->nlevel] = (L + KNN_CHUNK - 1) / KNN_CHUNK;
+    L = p->nchunk[p->nlevel] * p->kp;
+    ++p->nlevel;
+  }
+  size_t off = 0;
+  p->off_S = off;
+  off += align_up((size_t)B * p->ldS * sizeof(float), 256);
+  const size_t cand = p->nlevel > 0 ? (size_t)B * p->nchunk[0] * p->kp : 0;
+  for (int i = 0; i < 2; ++i) {
+    p->off_cv[i] = off; off += align_up(cand * sizeof(float), 256);
+    p->off_ci[i] = off; off += align_up(cand * sizeof(int32_t), 256);
+  }
+  p->total = off;
+  return true;
+}
+
+static int g_num_cu = 0;
+static int num_cus() {
+  if (g_num_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    g_num_cu = n;
+  }
+  return g_num_cu;
+}
+
+int knn_scores(const uint16_t* q, const uint16_t* g, int B, int N, int D, void* ws, size_t ws_bytes,
+               int k_for_plan, hipStream_t stream) {
+  KnnPlan p;
+  if (!q || !g || !ws) return VPR_ERR_INVALID_ARG;
+  if (!knn_plan(B, N, D, k_for_plan, &p)) return VPR_ERR_UNSUPPORTED;
+  if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(g)) & 15) return VPR_ERR_UNSUPPORTED;
+  float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + p.off_S);
+  const int slots = num_cus() * KNN_WG_PER_CU;
+  // Fully resident, balanced grid; never more workgroups than 16-row blocks of gallery.
+  int nwg = slots;
+  const int max_useful = (N + 15) / 16;
+  if (nwg > max_useful) nwg = max_useful;
+  constexpr size_t lds = 2 * (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
+  hipLaunchKernelGGL(knn_scores_kernel, dim3(nwg, p.Bpad / KNN_QT), dim3(256), lds, stream,
+                     q, g, S, B, N, D, p.ldS);
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+
+int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k, int index_base,
+               float* out_val, int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream) {
+  KnnPlan p;
+  if (!q || !g || !ws || !out_val || !out_idx) return VPR_ERR_INVALID_ARG;
+  if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
+  if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
+  char* w = static_cast<char*>(ws);
+  const float* cur_v = reinterpret_cast<float*>(w + p.off_S);
+  const int32_t* cur_i = nullptr;
+  long long ld = p.ldS;
+  int L = N;
+  for (int lev = 0; lev < p.nlevel; ++lev) {
+    float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
+    int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
+    hipLaunchKernelGGL(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
+                       cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]);
+    cur_v = ov; cur_i = oi;
+    L = p.nchunk[lev] * p.kp;
+    ld = L;
+  }
+  hipLaunchKernelGGL(knn_final_kernel, dim3(B), dim3(256), 0, stream,
+                     cur_v, cur_i, L, ld, q, g, D, k, p.kp, index_base, out_val, out_idx);
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+
+}  // namespace vpr
+
+using namespace vpr;
+
+extern "C" size_t vpr_knn_workspace_bytes(int B, int N, int D, int k) {
+  KnnPlan p;
+  return knn_plan(B, N, D, k, &p) ? p.total : 0;
+}
+
+extern "C" float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k, int* ld_out) {
+  KnnPlan p;
+  if (!workspace || !knn_plan(B, N, D, k, &p)) return nullptr;
+  if (ld_out) *ld_out = p.ldS;
+  return reinterpret_cast<float*>(static_cast<char*>(workspace) + p.off_S);
+}
+
+extern "C" int vpr_knn_scores(const uint16_t* q, const uint16_t* gallery, int B, int N, int D,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  // The plan's score-matrix offset does not depend on k; size checks use the caller's bytes.
+  return knn_scores(q, gallery, B, N, D, workspace, workspace_bytes, 1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                              int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return knn_select(q, gallery, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                            int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  KnnPlan p;
+  if (!knn_plan(B, N, D, k, &p)) return (B <= 0 || N <= 0 || D <= 0 || k <= 0) ? VPR_ERR_INVALID_ARG : VPR_ERR_UNSUPPORTED;
+  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
+  int st = knn_scores(q, gallery, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream));
+  if (st != VPR_OK) return st;
+  return knn_select(q, gallery, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vpr_topk_merge(const float* vals, const int32_t* idxs, int shards, int B, int k,
+                              float* out_val, int32_t* out_idx, void* stream) {
+  if (!vals || !idxs || !out_val || !out_idx || shards <= 0 || B <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
+  if (k > 128 || (long long)shards * k > 4096) return VPR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     vals, idxs, shards, B, k, out_val, out_idx);
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}

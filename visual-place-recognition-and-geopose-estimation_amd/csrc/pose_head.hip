@@ -1,0 +1,310 @@
+// pose_head.hip — regression / angle heads of the geopose path, f32 end to end.
+//
+// vpr_pose_head          Linear(D,hidden) -> ReLU -> Linear(hidden,n_out) [+ unit-normalise a pair]
+//   replaces DINOv2RegressionModel.regressor   dinov2salad/dinov2salad_validation.py:43-47,52
+//            Swin-Base MLP head (Dropout = identity in eval)  swin_transformer/val_and_test_swin_2.py:168-177
+//            sin/cos MLP head   angle_prediction/swin/swin_angle_finetuning_gemini.py:101-106
+//   hidden == 0: single Linear(D,n_out)       swin_transformer/swin_validation.py:41,46
+//            + F.normalize(dim=1,p=2,eps=1e-6) angle_prediction/swin/swin_angle_finetuning_sin_cos.py:56-62
+// vpr_ln_meanpool_head   HF SwinModel pooler (LayerNorm -> mean over tokens) + linear head
+//   replaces `outputs.pooler_output` + `self.regressor`  swin_transformer/swin_validation.py:43-46
+//
+// The first layer is a weight-streaming skinny GEMM (HBM/L2-bound on W1): split-K over the
+// grid, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 == an fmaf chain, cdna guide §3), partial slabs
+// summed in a fixed order by the epilogue kernel — bitwise reproducible run to run.
+#include <math.h>
+#include "vpr_common.cuh"
+#include "vpr_internal.h"
+
+namespace vpr {
+
+constexpr int PH_BT = 64;   // batch rows per workgroup (4 waves x 16)
+constexpr int PH_HT = 32;   // hidden units per workgroup (2 MFMA column blocks)
+
+__global__ __launch_bounds__(256) void pose_l1_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ part,
+    int B, int D, int hidden, int steps_per_slice) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h0 = blockIdx.x * PH_HT;
+  const int ks = blockIdx.y;
+  const int b0 = blockIdx.z * PH_BT + 16 * wave;
+  const int nsteps = D >> 4;                       // 16 k per step (one float4 per lane)
+  const int s_begin = ks * steps_per_slice;
+  const int s_end = min(nsteps, s_begin + steps_per_slice);
+  // operand maps of 16x16x4: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15].
+  // Each lane loads 4 consecutive k (one float4) and feeds element t to MFMA t: lanes of one
+  // k-group use the same 4 k values for A and for B, so the k permutation cancels.
+  const int r = lane & 15, kg = lane >> 4;
+  const int brow = min(b0 + r, B - 1);
+  const float4* xa = reinterpret_cast<const float4*>(x + (long long)brow * D) + kg;
+  const float4* wa = reinterpret_cast<const float4*>(W1 + (long long)(h0 + r) * D) + kg;
+  const float4* wb = reinterpret_cast<const float4*>(W1 + (long long)(h0 + 16 + r) * D) + kg;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int s = s_begin; s < s_end; ++s) {
+    const float4 a = xa[s * 4];
+    const float4 w0 = wa[s * 4];
+    const float4 w1 = wb[s * 4];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w1.w, acc1, 0, 0, 0);
+  }
+  // C/D: col (hidden) = lane&15, row (batch) = 4*(lane>>4) + e
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int b = b0 + 4 * kg + e;
+    if (b < B) {
+      float* p = part + ((long long)ks * B + b) * hidden + h0;
+      p[r] = acc0[e];
+      p[16 + r] = acc1[e];
+    }
+  }
+}
+
+__device__ __forceinline__ float block_sum_256p(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ void finish_outputs(float* outs, int n_out, int sincos_offset, float* dst) {
+  // F.normalize(p=2, dim=1, eps=1e-6) of the pair [off, off+1]: v / max(||v||, eps)
+  if (threadIdx.x == 0) {
+    if (sincos_offset >= 0 && sincos_offset + 1 < n_out) {
+      const float a = outs[sincos_offset], b = outs[sincos_offset + 1];
+      const float den = fmaxf(sqrtf(a * a + b * b), 1e-6f);
+      outs[sincos_offset] = a / den;
+      outs[sincos_offset + 1] = b / den;
+    }
+    for (int o = 0; o < n_out; ++o) dst[o] = outs[o];
+  }
+}
+
+// hidden > 0: one workgroup per batch row; sums the split-K slabs (fixed order), bias, ReLU,
+// second layer, optional pair normalise.
+__global__ __launch_bounds__(256) void pose_epilogue_kernel(
+    const float* __restrict__ part, int nslice, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
+    int B, int hidden, int n_out, int sincos_offset) {
+  __shared__ float red[4];
+  __shared__ float outs[8];
+  const int b = blockIdx.x;
+  float po[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) po[o] = 0.f;
+  for (int h = threadIdx.x; h < hidden; h += 256) {
+    float s = 0.f;
+    for (int ks = 0; ks < nslice; ++ks) s += part[((long long)ks * B + b) * hidden + h];
+    s = fmaxf(s + b1[h], 0.f);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < n_out) po[o] = fmaf(s, W2[(long long)o * hidden + h], po[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o < n_out) {   // n_out is uniform: every thread takes the same branches
+      const float tot = block_sum_256p(po[o], red);
+      if (threadIdx.x == 0) outs[o] = tot + b2[o];
+    }
+  }
+  __syncthreads();
+  finish_outputs(outs, n_out, sincos_offset, out + (long long)b * n_out);
+}
+
+// hidden == 0: out = W2 x + b2, one workgroup per batch row.
+__global__ __launch_bounds__(256) void pose_linear_kernel(
+    const float* __restrict__ x, const float* __restrict__ W2, const float* __restrict__ b2,
+    float* __restrict__ out, int D, int n_out, int sincos_offset) {
+  __shared__ float red[4];
+  __shared__ float outs[8];
+  const int b = blockIdx.x;
+  float po[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) po[o] = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float xv = x[(long long)b * D + d];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < n_out) po[o] = fmaf(xv, W2[(long long)o * D + d], po[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o < n_out) {
+      const float tot = block_sum_256p(po[o], red);
+      if (threadIdx.x == 0) outs[o] = tot + b2[o];
+    }
+  }
+  __syncthreads();
+  finish_outputs(outs, n_out, sincos_offset, out + (long long)b * n_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm -> mean over tokens -> optional linear head.  One workgroup per image, wave per
+// token (4 tokens in flight), lane holds VPL = H/64 elements as VPL/4 4-element vectors
+// (element = c*256 + lane*4 + e: 8-B bf16 / 16-B f32 loads, coalesced over the wave).
+// Two-pass statistics in registers (mean, then centred sum of squares) like torch's LayerNorm.
+// ---------------------------------------------------------------------------------------------
+template <int VPL, bool BF16>
+__global__ __launch_bounds__(256) void ln_meanpool_head_kernel(
+    const void* __restrict__ xin, int T, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ pooled_out,
+    const float* __restrict__ Wh, const float* __restrict__ bh, int n_out, int sincos_offset,
+    float* __restrict__ out) {
+  constexpr int H = VPL * 64;
+  constexpr int NV = VPL / 4;
+  __shared__ float pool[4][H];
+  __shared__ float outs[8];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  float gm[VPL], bt[VPL], accp[VPL];
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int h = c * 256 + lane * 4 + e;
+      gm[c * 4 + e] = gamma[h];
+      bt[c * 4 + e] = beta[h];
+      accp[c * 4 + e] = 0.f;
+    }
+
+  for (int t = wave; t < T; t += 4) {
+    float xv[VPL];
+    if (BF16) {
+      const uint16_t* row = reinterpret_cast<const uint16_t*>(xin) + ((long long)b * T + t) * H;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(row + c * 256 + lane * 4);
+        xv[c * 4 + 0] = bf16_bits_to_f32(q.x);
+        xv[c * 4 + 1] = bf16_bits_to_f32(q.y);
+        xv[c * 4 + 2] = bf16_bits_to_f32(q.z);
+        xv[c * 4 + 3] = bf16_bits_to_f32(q.w);
+      }
+    } else {
+      const float* row = reinterpret_cast<const float*>(xin) + ((long long)b * T + t) * H;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const float4 q = *reinterpret_cast<const float4*>(row + c * 256 + lane * 4);
+        xv[c * 4 + 0] = q.x; xv[c * 4 + 1] = q.y; xv[c * 4 + 2] = q.z; xv[c * 4 + 3] = q.w;
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += xv[i];
+    const float mean = wave_sum(s) / (float)H;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { const float d = xv[i] - mean; ss = fmaf(d, d, ss); }
+    const float var = wave_sum(ss) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) accp[i] += (xv[i] - mean) * rstd * gm[i] + bt[i];
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pool[wave][c * 256 + lane * 4 + e] = accp[c * 4 + e];
+  __syncthreads();
+  // fixed-order cross-wave sum; thread h keeps pooled[h] for the head below
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const float p = ((pool[0][h] + pool[1][h]) + (pool[2][h] + pool[3][h])) / (float)T;
+    pool[0][h] = p;
+    if (pooled_out) pooled_out[(long long)b * H + h] = p;
+  }
+  __syncthreads();
+  if (Wh == nullptr || n_out <= 0) return;
+  for (int o = wave; o < n_out; o += 4) {
+    float s = 0.f;
+    for (int h = lane; h < H; h += 64) s = fmaf(pool[0][h], Wh[(long long)o * H + h], s);
+    s = wave_sum(s);
+    if (lane == 0) outs[o] = s + bh[o];
+  }
+  __syncthreads();
+  finish_outputs(outs, n_out, sincos_offset, out + (long long)b * n_out);
+}
+
+static int pick_slices(int B, int D, int hidden) {
+  // aim at ~512 workgroups; each slice at least 8 MFMA k-steps (128 of D)
+  const int tiles = (hidden / PH_HT) * ((B + PH_BT - 1) / PH_BT);
+  int ks = (512 + tiles - 1) / tiles;
+  const int nsteps = D / 16;
+  const int max_ks = nsteps / 8 > 0 ? nsteps / 8 : 1;
+  if (ks > max_ks) ks = max_ks;
+  if (ks > 64) ks = 64;
+  if (ks < 1) ks = 1;
+  return ks;
+}
+
+}  // namespace vpr
+
+using namespace vpr;
+
+extern "C" size_t vpr_pose_head_workspace_bytes(int B, int D, int hidden, int n_out) {
+  (void)n_out;
+  if (B <= 0 || D <= 0 || hidden < 0) return 0;
+  if (hidden == 0) return 256;
+  return align_up((size_t)pick_slices(B, D, hidden) * B * hidden * sizeof(float), 256);
+}
+
+extern "C" int vpr_pose_head(const float* x, const float* W1, const float* b1, const float* W2,
+                             const float* b2, float* out, int B, int D, int hidden, int n_out,
+                             int sincos_offset, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !W2 || !b2 || !out || B <= 0 || D <= 0 || hidden < 0 || n_out < 1) return VPR_ERR_INVALID_ARG;
+  if (n_out > 8) return VPR_ERR_UNSUPPORTED;
+  if (hidden == 0) {
+    hipLaunchKernelGGL(pose_linear_kernel, dim3(B), dim3(256), 0, stream, x, W2, b2, out, D, n_out, sincos_offset);
+    return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  }
+  if (!W1 || !b1 || !workspace) return VPR_ERR_INVALID_ARG;
+  if ((D % 16) || (hidden % PH_HT)) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W1)) & 15) return VPR_ERR_UNSUPPORTED;
+  const int ks = pick_slices(B, D, hidden);
+  if (workspace_bytes < (size_t)ks * B * hidden * sizeof(float)) return VPR_ERR_WORKSPACE;
+  const int nsteps = D / 16;
+  const int sps = (nsteps + ks - 1) / ks;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(pose_l1_partial_kernel, dim3(hidden / PH_HT, ks, (B + PH_BT - 1) / PH_BT), dim3(256), 0,
+                     stream, x, W1, part, B, D, hidden, sps);
+  hipLaunchKernelGGL(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
+                     hidden, n_out, sincos_offset);
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+
+template <int VPL>
+static void launch_ln(const void* x, int bf16, int B, int T, const float* gamma, const float* beta, float eps,
+                      float* pooled, const float* Wh, const float* bh, int n_out, int so, float* out,
+                      hipStream_t stream) {
+  if (bf16)
+    hipLaunchKernelGGL((ln_meanpool_head_kernel<VPL, true>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
+                       eps, pooled, Wh, bh, n_out, so, out);
+  else
+    hipLaunchKernelGGL((ln_meanpool_head_kernel<VPL, false>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
+                       eps, pooled, Wh, bh, n_out, so, out);
+}
+
+extern "C" int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, int H, const float* gamma,
+                                    const float* beta, float eps, float* pooled_out, const float* Wh,
+                                    const float* bh, int n_out, int sincos_offset, float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !gamma || !beta || B <= 0 || T <= 0 || n_out < 0) return VPR_ERR_INVALID_ARG;
+  if (n_out > 8) return VPR_ERR_UNSUPPORTED;
+  if (n_out > 0 && Wh && (!bh || !out)) return VPR_ERR_INVALID_ARG;
+  if (!pooled_out && !(Wh && n_out > 0)) return VPR_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(x) & 15) return VPR_ERR_UNSUPPORTED;
+  switch (H) {
+    case 512:  launch_ln<8>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
+    case 768:  launch_ln<12>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
+    case 1024: launch_ln<16>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
+    case 1536: launch_ln<24>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
+    default: return VPR_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}

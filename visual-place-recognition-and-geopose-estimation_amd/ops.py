@@ -1,0 +1,283 @@
+"""Tensor-level wrappers over the C ABI (include/vpr_amd.h).
+
+Each function takes torch tensors that already live on the GPU, launches the HIP kernels on
+torch's current stream and returns torch tensors; PyTorch is used for device memory and streams
+only.  Any non-zero status raises RuntimeError — there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_WORKSPACES = {}
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need(t: torch.Tensor, dtype: torch.dtype, name: str, ndim: Optional[int] = None) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got {t.dim()}")
+
+
+def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
+    """Cached byte buffer per (device, name); grows, never shrinks.  One stream per device assumed."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ SALAD
+@dataclass
+class SaladWeights:
+    """Kernel-format SALAD weights (bf16 [out,in] matrices, f32 biases), all on one GPU.
+
+    w1_sc = cat(score.0.weight, cluster_features.0.weight) [2*hidden, C]; see include/vpr_amd.h.
+    """
+    w1_sc: torch.Tensor
+    b1_sc: torch.Tensor
+    w2_s: torch.Tensor
+    b2_s: torch.Tensor
+    w2_c: torch.Tensor
+    b2_c: torch.Tensor
+    w1_t: torch.Tensor
+    b1_t: torch.Tensor
+    w2_t: torch.Tensor
+    b2_t: torch.Tensor
+    dustbin: float = 1.0
+
+    def validate(self) -> Tuple[int, int, int, int, int]:
+        for n in ("w1_sc", "w2_s", "w2_c", "w1_t", "w2_t"):
+            _need(getattr(self, n), torch.bfloat16, n, 2)
+        for n in ("b1_sc", "b2_s", "b2_c", "b1_t", "b2_t"):
+            _need(getattr(self, n), torch.float32, n, 1)
+        hidden2, C = self.w1_sc.shape
+        hidden = hidden2 // 2
+        m, l, t = self.w2_s.shape[0], self.w2_c.shape[0], self.w2_t.shape[0]
+        ok = (self.w2_s.shape[1] == hidden and self.w2_c.shape[1] == hidden and
+              tuple(self.w1_t.shape) == (hidden, C) and self.w2_t.shape[1] == hidden and
+              self.b1_sc.numel() == 2 * hidden and self.b2_s.numel() == m and
+              self.b2_c.numel() == l and self.b1_t.numel() == hidden and self.b2_t.numel() == t)
+        if not ok:
+            raise RuntimeError("SaladWeights: inconsistent shapes")
+        return C, hidden, m, l, t
+
+    def c_struct(self) -> _lib.SaladWeightsC:
+        return _lib.SaladWeightsC(*[getattr(self, n).data_ptr() for n, _ in _lib.SaladWeightsC._fields_])
+
+
+def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int = 3,
+                    want_bf16: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """tokens [B, 1+n, C] bf16 (cls first) -> (descriptor f32 [B, t+l*m], bf16 copy or None)."""
+    _need(tokens, torch.bfloat16, "tokens", 3)
+    C, hidden, m, l, t = w.validate()
+    B, tpi, Ct = tokens.shape
+    if Ct != C:
+        raise RuntimeError(f"tokens have C={Ct}, weights expect {C}")
+    n = tpi - 1
+    L = _lib.lib()
+    nbytes = L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden)
+    ws = workspace("salad", nbytes, tokens.device)
+    out = torch.empty((B, t + l * m), dtype=torch.float32, device=tokens.device)
+    out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=tokens.device) if want_bf16 else None
+    cw = w.c_struct()
+    st = L.vpr_salad_aggregate(_ptr(tokens), B, tpi, C, ctypes.byref(cw), float(w.dustbin), m, l, t, hidden,
+                               int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_salad_aggregate")
+    return out, out16
+
+
+def salad_sinkhorn_aggregate(scores: torch.Tensor, feats: torch.Tensor, tokfeat: torch.Tensor,
+                             dustbin: float, sinkhorn_iters: int = 3,
+                             want_bf16: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """scores [B,n,m] f32, feats [B,n,l] f32, tokfeat [B,t] f32 -> descriptor (Sinkhorn stage only)."""
+    _need(scores, torch.float32, "scores", 3)
+    _need(feats, torch.float32, "feats", 3)
+    _need(tokfeat, torch.float32, "tokfeat", 2)
+    B, n, m = scores.shape
+    l, t = feats.shape[2], tokfeat.shape[1]
+    if feats.shape[:2] != (B, n) or tokfeat.shape[0] != B:
+        raise RuntimeError("salad_sinkhorn_aggregate: inconsistent shapes")
+    out = torch.empty((B, t + l * m), dtype=torch.float32, device=scores.device)
+    out16 = torch.empty_like(out, dtype=torch.bfloat16) if want_bf16 else None
+    st = _lib.lib().vpr_salad_sinkhorn_aggregate(_ptr(scores), _ptr(feats), _ptr(tokfeat), B, n, m, l, t,
+                                                 float(dustbin), int(sinkhorn_iters), _ptr(out), _ptr(out16),
+                                                 _stream())
+    _lib.check(st, "vpr_salad_sinkhorn_aggregate")
+    return out, out16
+
+
+def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                 out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """act(a @ w.T + bias): a [M,K] bf16, w [N,K] bf16 -> [M,N] f32 or bf16 (MFMA, f32 accumulate)."""
+    _need(a, torch.bfloat16, "a", 2)
+    _need(w, torch.bfloat16, "w", 2)
+    if bias is not None:
+        _need(bias, torch.float32, "bias", 1)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or (bias is not None and bias.numel() != N):
+        raise RuntimeError("gemm_nt_bf16: inconsistent shapes")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("gemm_nt_bf16: out_dtype must be float32 or bfloat16")
+    out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    st = _lib.lib().vpr_gemm_nt_bf16(_ptr(a), K, 0, 0, _ptr(w), K, _ptr(bias), int(relu), _ptr(out), N,
+                                     int(out_dtype == torch.bfloat16), M, N, K, _stream())
+    _lib.check(st, "vpr_gemm_nt_bf16")
+    return out
+
+
+# -------------------------------------------------------------------------------------------- kNN
+def knn_workspace(B: int, N: int, D: int, k: int, device: torch.device) -> torch.Tensor:
+    nbytes = _lib.lib().vpr_knn_workspace_bytes(B, N, D, k)
+    if nbytes == 0:
+        raise RuntimeError(f"vpr_knn: unsupported shape B={B} N={N} D={D} k={k} (need D % 64 == 0, 1 <= k <= 64)")
+    return workspace("knn", nbytes, device)
+
+
+def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0,
+             ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q [B,D] bf16, gallery [N,D] bf16 -> (scores f32 [B,k] descending, indices int32 [B,k])."""
+    _need(q, torch.bfloat16, "q", 2)
+    _need(gallery, torch.bfloat16, "gallery", 2)
+    B, D = q.shape
+    N = gallery.shape[0]
+    if gallery.shape[1] != D:
+        raise RuntimeError("knn_topk: q and gallery disagree on D")
+    if ws is None:
+        ws = knn_workspace(B, N, D, k, q.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
+    st = _lib.lib().vpr_knn_topk(_ptr(q), _ptr(gallery), B, N, D, int(k), int(index_base), _ptr(vals), _ptr(idx),
+                                 _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_knn_topk")
+    return vals, idx
+
+
+def knn_scores(q: torch.Tensor, gallery: torch.Tensor, ws: torch.Tensor) -> None:
+    """Stage 1 only (the HBM-bound score kernel); results stay in `ws`."""
+    _need(q, torch.bfloat16, "q", 2)
+    _need(gallery, torch.bfloat16, "gallery", 2)
+    B, D = q.shape
+    st = _lib.lib().vpr_knn_scores(_ptr(q), _ptr(gallery), B, gallery.shape[0], D, _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_knn_scores")
+
+
+def knn_select(q: torch.Tensor, gallery: torch.Tensor, k: int, ws: torch.Tensor,
+               index_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stage 2+3 (candidate selection, exact rescoring, ordering) on scores already in `ws`."""
+    B, D = q.shape
+    vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
+    st = _lib.lib().vpr_knn_select(_ptr(q), _ptr(gallery), B, gallery.shape[0], D, int(k), int(index_base),
+                                   _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_knn_select")
+    return vals, idx
+
+
+def knn_scores_view(ws: torch.Tensor, B: int, N: int, D: int, k: int) -> torch.Tensor:
+    """View of the score matrix S[B, N] inside a kNN workspace (tests)."""
+    ld = ctypes.c_int(0)
+    p = _lib.lib().vpr_knn_scores_ptr(_ptr(ws), B, N, D, k, ctypes.byref(ld))
+    if not p:
+        raise RuntimeError("vpr_knn_scores_ptr: unsupported shape")
+    off = p - ws.data_ptr()
+    flat = ws[off: off + B * ld.value * 4].view(torch.float32)
+    return flat.view(B, ld.value)[:, :N]
+
+
+def topk_merge(vals: torch.Tensor, idxs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """vals/idxs [shards, B, k] (per-shard top-k with global indices) -> merged [B, k]."""
+    _need(vals, torch.float32, "vals", 3)
+    _need(idxs, torch.int32, "idxs", 3)
+    if vals.shape != idxs.shape:
+        raise RuntimeError("topk_merge: vals and idxs shapes differ")
+    R, B, k = vals.shape
+    ov = torch.empty((B, k), dtype=torch.float32, device=vals.device)
+    oi = torch.empty((B, k), dtype=torch.int32, device=vals.device)
+    st = _lib.lib().vpr_topk_merge(_ptr(vals), _ptr(idxs), R, B, k, _ptr(ov), _ptr(oi), _stream())
+    _lib.check(st, "vpr_topk_merge")
+    return ov, oi
+
+
+# ------------------------------------------------------------------------------------------ heads
+def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Tensor], W2: torch.Tensor,
+              b2: torch.Tensor, sincos_offset: int = -1) -> torch.Tensor:
+    """W2 relu(W1 x + b1) + b2 in f32 (W1 None -> single Linear); optional unit-normalised pair."""
+    _need(x, torch.float32, "x", 2)
+    _need(W2, torch.float32, "W2", 2)
+    _need(b2, torch.float32, "b2", 1)
+    B, D = x.shape
+    n_out = W2.shape[0]
+    hidden = 0
+    if W1 is not None:
+        _need(W1, torch.float32, "W1", 2)
+        _need(b1, torch.float32, "b1", 1)
+        hidden = W1.shape[0]
+        if W1.shape[1] != D or b1.numel() != hidden or W2.shape[1] != hidden:
+            raise RuntimeError("pose_head: inconsistent MLP shapes")
+    elif W2.shape[1] != D:
+        raise RuntimeError("pose_head: W2 must be [n_out, D] for the linear head")
+    if b2.numel() != n_out:
+        raise RuntimeError("pose_head: b2 size")
+    L = _lib.lib()
+    ws = workspace("pose", L.vpr_pose_head_workspace_bytes(B, D, hidden, n_out), x.device)
+    out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    st = L.vpr_pose_head(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), B, D, hidden, n_out,
+                         int(sincos_offset), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_pose_head")
+    return out
+
+
+def ln_meanpool_head(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                     Wh: Optional[torch.Tensor] = None, bh: Optional[torch.Tensor] = None,
+                     sincos_offset: int = -1, want_pooled: bool = True
+                     ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """x [B,T,H] (bf16|f32): pooled = mean_t LayerNorm(x); out = Wh pooled + bh.  -> (pooled, out)."""
+    if x.dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("ln_meanpool_head: x must be bf16 or f32")
+    _need(x, x.dtype, "x", 3)
+    _need(gamma, torch.float32, "gamma", 1)
+    _need(beta, torch.float32, "beta", 1)
+    B, T, H = x.shape
+    n_out = 0
+    if Wh is not None:
+        _need(Wh, torch.float32, "Wh", 2)
+        _need(bh, torch.float32, "bh", 1)
+        n_out = Wh.shape[0]
+        if Wh.shape[1] != H or bh.numel() != n_out:
+            raise RuntimeError("ln_meanpool_head: head shapes")
+    pooled = torch.empty((B, H), dtype=torch.float32, device=x.device) if (want_pooled or Wh is None) else None
+    out = torch.empty((B, n_out), dtype=torch.float32, device=x.device) if Wh is not None else None
+    st = _lib.lib().vpr_ln_meanpool_head(_ptr(x), int(x.dtype == torch.bfloat16), B, T, H, _ptr(gamma), _ptr(beta),
+                                         float(eps), _ptr(pooled), _ptr(Wh), _ptr(bh), n_out, int(sincos_offset),
+                                         _ptr(out), _stream())
+    _lib.check(st, "vpr_ln_meanpool_head")
+    return pooled, out
+
+
+def f32_to_bf16(src: torch.Tensor) -> torch.Tensor:
+    _need(src, torch.float32, "src")
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    st = _lib.lib().vpr_f32_to_bf16(_ptr(src), _ptr(dst), src.numel(), _stream())
+    _lib.check(st, "vpr_f32_to_bf16")
+    return dst
