@@ -1,0 +1,216 @@
+"""End-to-end throughput of the VPR + geopose hot path on N MI355X GPUs (one process per GPU).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one batch of B synthetic 3x224x224 images per GPU through DINOv2 ViT-L/14 (PyTorch-ROCm,
+random init) -> SALAD aggregation (HIP) -> bf16 cosine top-k against the 100k-row synthetic
+gallery, row-sharded over the ranks (HIP; RCCL all-gather of queries and of per-shard top-k,
+on-device merge) -> fused (lat, lon, sin, cos) head (HIP).  Weak scaling: B per GPU is fixed.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
+hand-written kernel (the HBM-bound kNN score kernel, timed live with HIP events inside the timed
+region) and `cpu_baseline` (oracle/ + the same backbone on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D_DESC = 8448
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_gallery_shard(rows: int, seed: int, dev) -> torch.Tensor:
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = torch.empty((rows, D_DESC), dtype=torch.bfloat16, device=dev)
+    step = 16384
+    for lo in range(0, rows, step):
+        n = min(step, rows - lo)
+        out[lo:lo + n] = torch.nn.functional.normalize(torch.randn(n, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
+    return out
+
+
+def cpu_baseline(ext_state, arch, head_mods, images_cpu, gallery_sample_cpu, n_total, k):
+    """Same op sequence on the host: backbone (PyTorch CPU fp32) + oracle SALAD / kNN / head.
+    Bounded sample: `images_cpu` (a few images) and a slice of the gallery, scaled to n_total."""
+    from oracle import heads as oheads, knn as oknn, salad as osalad
+    from vpr_amd.modules import DinoV2Salad
+    threads = min(os.cpu_count(), 16)          # the GPU box gives one GPU's job a 16-core share
+    torch.set_num_threads(threads)
+    ext = DinoV2Salad(arch).float().eval()
+    ext.load_state_dict(ext_state)
+    b = images_cpu.shape[0]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        tokens = ext.backbone(images_cpu.float())
+    t_backbone = time.perf_counter() - t0
+    agg = ext.aggregator
+    m2 = lambda w: w.detach().reshape(w.shape[0], -1).float()
+    w = dict(w1_sc=torch.cat([m2(agg.score[0].weight), m2(agg.cluster_features[0].weight)], 0),
+             b1_sc=torch.cat([agg.score[0].bias, agg.cluster_features[0].bias], 0).detach().float(),
+             w2_s=m2(agg.score[3].weight), b2_s=agg.score[3].bias.detach().float(),
+             w2_c=m2(agg.cluster_features[3].weight), b2_c=agg.cluster_features[3].bias.detach().float(),
+             w1_t=m2(agg.token_features[0].weight), b1_t=agg.token_features[0].bias.detach().float(),
+             w2_t=m2(agg.token_features[2].weight), b2_t=agg.token_features[2].bias.detach().float())
+    t0 = time.perf_counter()
+    desc = osalad.salad_aggregate(tokens, w, float(agg.dust_bin), 3, dtype=torch.float32, quantize=False)
+    t_salad = time.perf_counter() - t0
+    q = desc.to(torch.bfloat16)
+    t0 = time.perf_counter()
+    s = q.float() @ gallery_sample_cpu.float().T          # fp32 brute force, all cores
+    torch.topk(s, k, dim=1)
+    t_knn = (time.perf_counter() - t0) * (n_total / gallery_sample_cpu.shape[0])
+    W1, b1, W2, b2 = head_mods
+    t0 = time.perf_counter()
+    oheads.mlp_head(desc, W1, b1, W2, b2, 2, dtype=torch.float32)
+    t_head = time.perf_counter() - t0
+    total = t_backbone + t_salad + t_knn + t_head
+    return {"value": b / total, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{b} images (backbone {t_backbone:.2f}s, SALAD {t_salad:.2f}s, head {t_head:.3f}s) + "
+                      f"fp32 brute-force kNN on {gallery_sample_cpu.shape[0]} of {n_total} gallery rows scaled x"
+                      f"{n_total / gallery_sample_cpu.shape[0]:.0f} ({t_knn:.2f}s); torch {torch.__version__} CPU, "
+                      f"{threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--gallery", type=int, default=100_000, help="total gallery rows (sharded over ranks)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--arch", default="vit_large")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vpr_amd import _lib, ops
+    _lib.lib()
+    from vpr_amd.modules import DinoV2Salad, FusedGeoPoseHead
+    from vpr_amd.pipeline import VPRGeoPosePipeline
+    from vpr_amd.retrieval import ShardedGallery, shard_bounds
+
+    torch.manual_seed(0)                                   # identical weights on every rank
+    ext32 = DinoV2Salad(a.arch).eval()
+    for p in ext32.aggregator.parameters():                # SALAD weights ~ N(0, 0.02), dustbin 1
+        if p.dim() > 0:
+            nn.init.normal_(p, std=0.02)
+    ext_state = {k: v.clone() for k, v in ext32.state_dict().items()}
+    ext = ext32.to(dev).to(torch.bfloat16)
+    pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))
+    ang = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))
+    head = FusedGeoPoseHead(pos.to(dev), ang.to(dev), normalize=True)
+    head_cpu = [t.cpu() for t in head.pack()]
+
+    lo, hi = shard_bounds(a.gallery, rank, world)
+    shard = make_gallery_shard(hi - lo, 1 + rank, dev)
+    gallery = ShardedGallery(shard, a.gallery, rank, world)
+    pipe = VPRGeoPosePipeline(ext, head, gallery, a.k)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        pipe.step(images)
+    pipe.knn_events = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = pipe.step(images)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    knn_ms = sorted(e0.elapsed_time(e1) for e0, e1 in pipe.knn_events)
+    knn_avg_s = sum(knn_ms) / len(knn_ms) * 1e-3
+    pipe.knn_events = None
+    n_shard, bq = hi - lo, a.batch * world
+    alg_bytes = n_shard * D_DESC * 2 + bq * D_DESC * 2 + bq * a.k * 8      # SURVEY §8d per query batch
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc.json")
+    if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64:
+        with open(pmc) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+
+    if rank == 0:
+        # planted-positive Recall@1 on this rank's shard (outside the timed region)
+        gp = torch.Generator(device=dev).manual_seed(7)
+        pos_idx = torch.randint(0, n_shard, (a.batch,), device=dev, generator=gp)
+        qn = torch.nn.functional.normalize(shard[pos_idx].float() + 0.1 * torch.randn(a.batch, D_DESC, device=dev, generator=gp), dim=1)
+        _, ti = ops.knn_topk(qn.to(torch.bfloat16), shard, 1, lo)
+        recall1 = float((ti[:, 0].long() == pos_idx + lo).double().mean())
+
+        # per-stage device time (one extra step each, outside the timed region)
+        def stage_ms(fn, n=3):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                r = fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n, r
+        stages = {}
+        stages["backbone_ms"], tokens = stage_ms(lambda: ext.tokens(images))
+        stages["salad_ms"], (desc, desc16) = stage_ms(lambda: ext.aggregator(tokens, want_bf16=True))
+        if world == 1:
+            stages["knn_ms"], _ = stage_ms(lambda: ops.knn_topk(desc16, shard, a.k))
+        stages["head_ms"], _ = stage_ms(lambda: head(desc))
+
+        res = {
+            "metric": "images/sec end-to-end (backbone->SALAD->kNN->pose)",
+            "value": a.steps * a.batch * world / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"DINOv2 {a.arch}/14 (random init) + SALAD + bf16 kNN k={a.k} over a "
+                                   f"{a.gallery}-row x {D_DESC} synthetic gallery sharded {world} way(s) + fused "
+                                   f"(lat,lon,sin,cos) head; 3x224x224 bf16 images",
+                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "gallery_rows": a.gallery,
+                       "k": a.k, "parallelism": f"dp{world}+gallery-shard{world}"},
+            "roofline": {"bound": "hbm", "kernel": "knn_scores_kernel",
+                         "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes},
+            "recall_at_1": recall1,
+            "stages": stages,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            sample = shard[: min(20000, n_shard)].cpu()
+            res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images[:2].cpu(), sample, a.gallery, a.k)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,10 @@ There is no fallback: if the library is missing, `lib()` raises with the build c
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  MUST precede loading libvpr_amd.so: the library has to bind to the HIP
+              # runtime PyTorch ships (torch/lib/libamdhip64.so), not to a second copy from /opt/rocm —
+              # two runtimes in one process make every launch fail with hipErrorNoDevice.
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t,
                     c_void_p)
 

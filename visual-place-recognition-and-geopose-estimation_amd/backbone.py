@@ -1,0 +1,74 @@
+"""DINOv2 ViT backbone in plain PyTorch-ROCm (plumbing: the hand-written HIP path starts at the
+token tensor it returns).
+
+Stands in for the backbone half of `torch.hub.load("serizba/salad", "dinov2_salad")`
+(dinov2salad/dinov2salad_validation.py:65), which wraps facebookresearch/dinov2 ViT-B/14 and
+hands SALAD the final-norm patch tokens + cls token.  Architecture only (random init; no weights
+exist offline): patch-14 conv embed, cls token, learned position embedding, pre-norm blocks with
+LayerScale, final LayerNorm.  Returns tokens [B, 1+n, C] with the cls token in row 0 — the
+layout vpr_salad_aggregate consumes directly (no permute to [B,C,16,16]).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+CONFIGS = {
+    # name: (embed_dim, depth, heads)
+    "vit_small": (384, 12, 6),
+    "vit_base": (768, 12, 12),       # what the reference's hub entry uses (C = 768)
+    "vit_large": (1024, 24, 16),     # BASELINE.json north star (C = 1024)
+}
+
+
+class Block(nn.Module):
+    def __init__(self, dim: int, heads: int, mlp_ratio: float = 4.0, init_values: float = 1e-5):
+        super().__init__()
+        self.heads = heads
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+        self.ls1 = nn.Parameter(init_values * torch.ones(dim))
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.fc1 = nn.Linear(dim, int(dim * mlp_ratio))
+        self.fc2 = nn.Linear(int(dim * mlp_ratio), dim)
+        self.ls2 = nn.Parameter(init_values * torch.ones(dim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, T, C = x.shape
+        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x = x + self.ls1 * self.proj(a.transpose(1, 2).reshape(B, T, C))
+        x = x + self.ls2 * self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        return x
+
+
+class DinoV2(nn.Module):
+    def __init__(self, arch: str = "vit_large", img_size: int = 224, patch: int = 14):
+        super().__init__()
+        dim, depth, heads = CONFIGS[arch]
+        self.embed_dim = dim
+        self.patch = patch
+        self.num_patches = (img_size // patch) ** 2
+        self.patch_embed = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, 1 + self.num_patches, dim))
+        self.blocks = nn.ModuleList(Block(dim, heads) for _ in range(depth))
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.normal_(self.cls_token, std=1e-6)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous."""
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return self.norm(x).contiguous()
+
+    def flops_per_image(self) -> float:
+        T, C, L = 1 + self.num_patches, self.embed_dim, len(self.blocks)
+        per_block = 2 * T * C * 3 * C + 2 * T * C * C + 4 * T * T * C + 2 * 2 * T * C * 4 * C
+        return L * per_block + 2 * self.num_patches * C * 3 * self.patch * self.patch

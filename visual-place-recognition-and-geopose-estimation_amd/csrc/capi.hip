@@ -53,7 +53,7 @@ extern "C" int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count,
   long long blocks = ((count >> 2) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, dst, count);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, dst, count));
+  return VPR_OK;
 }

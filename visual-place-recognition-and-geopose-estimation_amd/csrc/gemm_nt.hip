@@ -141,17 +141,17 @@ int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_gro
   if (N > 64) {
     const int tiles_n = (N + 127) / 128;
     constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
+    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
                        A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
-                       M, N, K, tiles_m, tiles_n);
+                       M, N, K, tiles_m, tiles_n));
   } else {
     const int tiles_n = 1;
     constexpr size_t lds = 2 * (128 + 64) * TILE_ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 4, 1>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
+    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<64, 4, 1>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
                        A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
-                       M, N, K, tiles_m, tiles_n);
+                       M, N, K, tiles_m, tiles_n));
   }
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  return VPR_OK;
 }
 
 }  // namespace vpr

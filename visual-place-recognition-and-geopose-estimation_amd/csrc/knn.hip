@@ -7,10 +7,10 @@
 //   1. knn_scores_kernel   S[b,n] = <q_b, g_n>   — HBM-bound stream of the gallery, MFMA
 //                          (v_mfma_f32_16x16x32_bf16) used only because a 64-query tile needs
 //                          64 FLOP per gallery byte.  THE dominant kernel (roofline: HBM).
-//   2. select_kernel       per (query, 4096-score chunk): top-KP candidates by the MFMA score
-//                          (KP = oversampled k), iterated until <= 4096 candidates remain.
-//   3. final_kernel        per query: top-KP of the candidates, EXACT rescoring of those KP rows
-//                          (bf16 products accumulated in f64, fixed order), final ordering by
+//   2. knn_select_kernel   per (query, 4096-score chunk): top-KP candidates by the MFMA score
+//                          (KP = oversampled k), repeated until one chunk is left -> [B][KP].
+//   3. knn_rescore_kernel  per query: EXACT rescoring of those KP rows (bf16 products
+//                          accumulated in f64, fixed order), final ordering by
 //                          (f32(score) desc, index asc), write top-k.
 // The exact rescoring makes the result independent of MFMA accumulation order: indices are
 // bit-exact against oracle/knn.py as long as the true top-k lie inside the approximate top-KP
@@ -155,44 +155,55 @@ __device__ __forceinline__ unsigned long long make_key(float v, int idx) {
 __device__ __forceinline__ int key_idx(unsigned long long k) { return 0x7fffffff - (int)(uint32_t)k; }
 __device__ __forceinline__ float key_val(unsigned long long k) { return f32_from_orderable((uint32_t)(k >> 32)); }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(v, o, 64);
-    v = other > v ? other : v;
-  }
-  return v;
-}
-
 constexpr unsigned long long KEY_DEAD = 0ull;   // below every real key (orderable(-inf) > 0)
+constexpr int SEL_CAP = 4096;                   // candidate list capacity (= elements per block)
 
-// keys[16] per thread; emits the kp largest keys in descending order into out_keys (LDS or
-// global, visible to the whole block after the call).  `red` is 4 u64 of LDS scratch.
-template <typename OutPtr>
-__device__ __forceinline__ void block_topk(unsigned long long (&keys)[16], int kp,
-                                           unsigned long long* red, OutPtr out_keys) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+struct SelectSmem {
+  unsigned long long tmax[256];
+  unsigned long long cand[SEL_CAP];
+  unsigned long long outk[128];
+  unsigned long long thr;
+  int cnt;
+};
+
+// Block-wide top-kp of <= 4096 unique keys held 16 per thread, without a serial argmax loop:
+//   a. every thread publishes the max of its 16 keys;
+//   b. the kp-th largest thread-max T (found by rank counting) is a lower bound of the kp-th
+//      largest key overall, so every top-kp key is >= T;
+//   c. keys >= T are appended to an LDS list (typically kp..2kp of them);
+//   d. each listed key counts the listed keys above it = its rank; ranks < kp go to outk[rank].
+// outk[0..kp) is complete (KEY_DEAD-padded) and visible to the whole block on return.
+__device__ __forceinline__ void block_select(const unsigned long long (&keys)[16], int kp, SelectSmem& sm) {
+  const int tid = threadIdx.x;
   unsigned long long best = KEY_DEAD;
 #pragma unroll
   for (int i = 0; i < 16; ++i) best = keys[i] > best ? keys[i] : best;
-#pragma unroll 1
-  for (int r = 0; r < kp; ++r) {
-    const unsigned long long wbest = wave_max_u64(best);
-    if (lane == 0) red[wave] = wbest;
-    __syncthreads();
-    unsigned long long top = red[0];
+  sm.tmax[tid] = best;
+  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
+  if (tid < kp) sm.outk[tid] = KEY_DEAD;
+  __syncthreads();
+  int rank = 0;
+  for (int s = 0; s < 256; s += 2) {
+    const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
+    rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
+  }
+  if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;   // keys are unique: at most one writer
+  __syncthreads();
+  const unsigned long long T = sm.thr;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) top = red[w] > top ? red[w] : top;
-    __syncthreads();
-    if (threadIdx.x == 0) out_keys[r] = top;
-    if (best == top && top != KEY_DEAD) {   // keys are unique (index is part of the key)
-      best = KEY_DEAD;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (keys[i] == top) keys[i] = KEY_DEAD;
-        best = keys[i] > best ? keys[i] : best;
-      }
+  for (int i = 0; i < 16; ++i) {
+    if (keys[i] >= T) {
+      const int pos = atomicAdd(&sm.cnt, 1);
+      sm.cand[pos] = keys[i];
     }
+  }
+  __syncthreads();
+  const int c = sm.cnt;
+  for (int ci = tid; ci < c; ci += 256) {
+    const unsigned long long mine = sm.cand[ci];
+    int r = 0;
+    for (int cj = 0; cj < c; ++cj) r += sm.cand[cj] > mine ? 1 : 0;
+    if (r < kp) sm.outk[r] = mine;
   }
   __syncthreads();
 }
@@ -221,88 +232,90 @@ __device__ __forceinline__ void load_keys(unsigned long long (&keys)[16], const 
   }
 }
 
-// 2. select: grid (chunks, B).  in_idx == nullptr -> index = position (+0); else explicit.
+// 2. select: grid (chunks, B).  in_idx == nullptr -> index = position; else explicit.
+// Output [B][nchunk][kp] (value, index), KEY_DEAD -> (-inf, -1).
 __global__ __launch_bounds__(256) void knn_select_kernel(
     const float* __restrict__ in_val, const int32_t* __restrict__ in_idx, int L, long long ld_in,
     float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk) {
-  __shared__ unsigned long long red[4];
-  __shared__ unsigned long long outk[128];
+  __shared__ SelectSmem sm;
   const int c = blockIdx.x, b = blockIdx.y;
   const float* v = in_val + (long long)b * ld_in;
   const int32_t* ix = in_idx ? in_idx + (long long)b * ld_in : nullptr;
   unsigned long long keys[16];
   load_keys(keys, v, ix, L, c * KNN_CHUNK);
-  block_topk(keys, kp, red, outk);
+  block_select(keys, kp, sm);
   if ((int)threadIdx.x < kp) {
-    const unsigned long long k = outk[threadIdx.x];
+    const unsigned long long k = sm.outk[threadIdx.x];
     const long long o = ((long long)b * nchunk + c) * kp + threadIdx.x;
     out_val[o] = k == KEY_DEAD ? -INFINITY : key_val(k);
     out_idx[o] = k == KEY_DEAD ? -1 : key_idx(k);
   }
 }
 
-// 3. final: grid (B).  Candidates (<= 4096) -> top-KP -> exact f64 rescoring -> order -> top-k.
-__global__ __launch_bounds__(256) void knn_final_kernel(
-    const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, int L, long long ld_in,
-    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G, int D, int k, int kp,
-    int index_base, float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
-  __shared__ unsigned long long red[4];
-  __shared__ unsigned long long outk[128];
+// 3. rescore + order: grid (B), 1024 threads.  cand_idx [B][kp] are the approximate top-kp
+// gallery rows of the query (-1 = padding).  Wave w rescoring candidates w, w+16, ...: exact
+// score = sum of bf16*bf16 products in f64 (each product exact), fixed order (4 lane-strided
+// partial sums, combined, then a butterfly) -> independent of how the candidate was found.
+// Final order by (f32(exact) desc, index asc), rank by counting, top-k written.
+__global__ __launch_bounds__(1024) void knn_rescore_kernel(
+    const int32_t* __restrict__ cand_idx, const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G,
+    int D, int k, int kp, int index_base, float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
   __shared__ float exact[128];
+  __shared__ int cidx[128];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* v = cand_val + (long long)b * ld_in;
-  const int32_t* ix = cand_idx ? cand_idx + (long long)b * ld_in : nullptr;
-  unsigned long long keys[16];
-  load_keys(keys, v, ix, L, 0);
-  block_topk(keys, kp, red, outk);
-
-  // Exact rescoring: wave w takes candidates w, w+4, ...; lane strides over 16-B chunks of the
-  // two rows; bf16*bf16 is exact in f64 and the f64 sum order is fixed (lane-strided, then a
-  // butterfly), so the result does not depend on how the candidate was found.
+  if ((int)threadIdx.x < kp) cidx[threadIdx.x] = cand_idx[(long long)b * kp + threadIdx.x];
+  __syncthreads();
   const uint16_t* qrow = Q + (long long)b * D;
   const int nchunks = D >> 3;
-  for (int c = wave; c < kp; c += 4) {
-    const unsigned long long key = outk[c];
+  for (int c = wave; c < kp; c += 16) {
+    const int id = cidx[c];
     float s = -INFINITY;
-    if (key != KEY_DEAD) {
-      const uint16_t* grow = G + (long long)key_idx(key) * D;
-      double accd = 0.0;
-      for (int ch = lane; ch < nchunks; ch += 64) {
-        const s16x8 qa = *reinterpret_cast<const s16x8*>(qrow + ch * 8);
-        const s16x8 ga = *reinterpret_cast<const s16x8*>(grow + ch * 8);
+    if (id >= 0) {   // wave-uniform
+      const uint16_t* grow = G + (long long)id * D;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int ch0 = lane; ch0 < nchunks; ch0 += 256) {
+        s16x8 qa[4], ga[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          accd = fma((double)bf16_bits_to_f32((uint16_t)qa[j]), (double)bf16_bits_to_f32((uint16_t)ga[j]), accd);
+        for (int u = 0; u < 4; ++u) {
+          const int ch = ch0 + 64 * u;
+          const int chc = ch < nchunks ? ch : ch0;          // clamp: always a valid address
+          qa[u] = *reinterpret_cast<const s16x8*>(qrow + chc * 8);
+          ga[u] = *reinterpret_cast<const s16x8*>(grow + chc * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ch0 + 64 * u < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              acc[u] = fma((double)bf16_bits_to_f32((uint16_t)qa[u][j]),
+                           (double)bf16_bits_to_f32((uint16_t)ga[u][j]), acc[u]);
+          }
+        }
       }
-      accd = wave_sum_f64(accd);
-      s = (float)accd;
+      const double tot = wave_sum_f64((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      s = (float)tot;
     }
     if (lane == 0) exact[c] = s;
   }
   __syncthreads();
-
-  // Final ordering by (exact f32 score desc, index asc): rank by counting.
   if ((int)threadIdx.x < kp) {
     const int i = threadIdx.x;
-    const unsigned long long ki = outk[i];
+    const int id = cidx[i];
     int rank;
-    if (ki == KEY_DEAD) {
-      // padding entries keep their (stable) position behind every real entry
-      rank = i;
+    if (id < 0) {
+      rank = i;    // padding sits behind every real entry already (select output is ordered)
     } else {
-      const unsigned long long mine = make_key(exact[i], key_idx(ki));
+      const unsigned long long mine = make_key(exact[i], id);
       rank = 0;
       for (int j = 0; j < kp; ++j) {
-        const unsigned long long kj = outk[j];
-        if (kj == KEY_DEAD) continue;
-        const unsigned long long other = make_key(exact[j], key_idx(kj));
-        rank += other > mine ? 1 : 0;
+        const int jd = cidx[j];
+        rank += (jd >= 0 && make_key(exact[j], jd) > mine) ? 1 : 0;
       }
     }
     if (rank < k) {
-      out_val[(long long)b * k + rank] = ki == KEY_DEAD ? -INFINITY : exact[i];
-      out_idx[(long long)b * k + rank] = ki == KEY_DEAD ? -1 : key_idx(ki) + index_base;
+      out_val[(long long)b * k + rank] = id < 0 ? -INFINITY : exact[i];
+      out_idx[(long long)b * k + rank] = id < 0 ? -1 : id + index_base;
     }
   }
 }
@@ -311,8 +324,7 @@ __global__ __launch_bounds__(256) void knn_final_kernel(
 __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float* __restrict__ vals, const int32_t* __restrict__ idxs, int shards, int B, int k,
     float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
-  __shared__ unsigned long long red[4];
-  __shared__ unsigned long long outk[128];
+  __shared__ SelectSmem sm;
   const int b = blockIdx.x;
   const int L = shards * k;
   unsigned long long keys[16];
@@ -326,9 +338,9 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
     const float val = vals[o];
     keys[i] = (p < L && id >= 0) ? make_key(val, id) : KEY_DEAD;
   }
-  block_topk(keys, k, red, outk);
+  block_select(keys, k, sm);
   if ((int)threadIdx.x < k) {
-    const unsigned long long key = outk[threadIdx.x];
+    const unsigned long long key = sm.outk[threadIdx.x];
     out_val[(long long)b * k + threadIdx.x] = key == KEY_DEAD ? -INFINITY : key_val(key);
     out_idx[(long long)b * k + threadIdx.x] = key == KEY_DEAD ? -1 : key_idx(key);
   }
@@ -349,19 +361,22 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
   p->Bpad = (B + KNN_QT - 1) / KNN_QT * KNN_QT;
   p->ldS = (N + 63) / 64 * 64;
   p->kp = knn_kp(k);
+  // select levels: each turns L entries per query into ceil(L/4096)*kp; the last level has one
+  // chunk, so its output is the [B][kp] candidate list the rescoring kernel takes.
   p->nlevel = 0;
   int L = N;
-  while (L > KNN_CHUNK) {
+  for (;;) {
     if (p->nlevel >= 4) return false;
     p->L[p->nlevel] = L;
     p->nchunk[p->nlevel] = (L + KNN_CHUNK - 1) / KNN_CHUNK;
     L = p->nchunk[p->nlevel] * p->kp;
     ++p->nlevel;
+    if (p->nchunk[p->nlevel - 1] == 1) break;
   }
   size_t off = 0;
   p->off_S = off;
   off += align_up((size_t)B * p->ldS * sizeof(float), 256);
-  const size_t cand = p->nlevel > 0 ? (size_t)B * p->nchunk[0] * p->kp : 0;
+  const size_t cand = (size_t)B * p->nchunk[0] * p->kp;
   for (int i = 0; i < 2; ++i) {
     p->off_cv[i] = off; off += align_up(cand * sizeof(float), 256);
     p->off_ci[i] = off; off += align_up(cand * sizeof(int32_t), 256);
@@ -396,9 +411,9 @@ int knn_scores(const uint16_t* q, const uint16_t* g, int B, int N, int D, void* 
   const int max_useful = (N + 15) / 16;
   if (nwg > max_useful) nwg = max_useful;
   constexpr size_t lds = 2 * (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
-  hipLaunchKernelGGL(knn_scores_kernel, dim3(nwg, p.Bpad / KNN_QT), dim3(256), lds, stream,
-                     q, g, S, B, N, D, p.ldS);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel, dim3(nwg, p.Bpad / KNN_QT), dim3(256), lds, stream,
+                     q, g, S, B, N, D, p.ldS));
+  return VPR_OK;
 }
 
 int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k, int index_base,
@@ -415,15 +430,15 @@ int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k,
   for (int lev = 0; lev < p.nlevel; ++lev) {
     float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
-    hipLaunchKernelGGL(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
-                       cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]);
+    VPR_TRY_LAUNCH(launch_kernel(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
+                       cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]));
     cur_v = ov; cur_i = oi;
     L = p.nchunk[lev] * p.kp;
     ld = L;
   }
-  hipLaunchKernelGGL(knn_final_kernel, dim3(B), dim3(256), 0, stream,
-                     cur_v, cur_i, L, ld, q, g, D, k, p.kp, index_base, out_val, out_idx);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel, dim3(B), dim3(1024), 0, stream,
+                     cur_i, q, g, D, k, p.kp, index_base, out_val, out_idx));
+  return VPR_OK;
 }
 
 }  // namespace vpr
@@ -471,7 +486,7 @@ extern "C" int vpr_topk_merge(const float* vals, const int32_t* idxs, int shards
                               float* out_val, int32_t* out_idx, void* stream) {
   if (!vals || !idxs || !out_val || !out_idx || shards <= 0 || B <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
   if (k > 128 || (long long)shards * k > 4096) return VPR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     vals, idxs, shards, B, k, out_val, out_idx);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(topk_merge_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     vals, idxs, shards, B, k, out_val, out_idx));
+  return VPR_OK;
 }

@@ -20,6 +20,7 @@ namespace vpr {
 
 constexpr int PH_BT = 64;   // batch rows per workgroup (4 waves x 16)
 constexpr int PH_HT = 32;   // hidden units per workgroup (2 MFMA column blocks)
+constexpr int PH_CH = 12;   // k-steps (16 of D each) loaded ahead of their MFMAs
 
 __global__ __launch_bounds__(256) void pose_l1_partial_kernel(
     const float* __restrict__ x, const float* __restrict__ W1, float* __restrict__ part,
@@ -40,19 +41,30 @@ __global__ __launch_bounds__(256) void pose_l1_partial_kernel(
   const float4* wa = reinterpret_cast<const float4*>(W1 + (long long)(h0 + r) * D) + kg;
   const float4* wb = reinterpret_cast<const float4*>(W1 + (long long)(h0 + 16 + r) * D) + kg;
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = s_begin; s < s_end; ++s) {
-    const float4 a = xa[s * 4];
-    const float4 w0 = wa[s * 4];
-    const float4 w1 = wb[s * 4];
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w1.x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0.y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w1.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w1.z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0.w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w1.w, acc1, 0, 0, 0);
+  // PH_CH steps of loads (3 x 16 B per lane each) are issued before their MFMAs, so a slice is
+  // a few round trips to HBM/L2 instead of one per step.
+  for (int s0 = s_begin; s0 < s_end; s0 += PH_CH) {
+    float4 a[PH_CH], w0[PH_CH], w1[PH_CH];
+#pragma unroll
+    for (int i = 0; i < PH_CH; ++i) {
+      const int s = min(s0 + i, s_end - 1);
+      a[i] = xa[s * 4];
+      w0[i] = wa[s * 4];
+      w1[i] = wb[s * 4];
+    }
+#pragma unroll
+    for (int i = 0; i < PH_CH; ++i) {
+      if (s0 + i < s_end) {   // wave-uniform
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, w0[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, w1[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, w0[i].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, w1[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, w0[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, w1[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w0[i].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, w1[i].w, acc1, 0, 0, 0);
+      }
+    }
   }
   // C/D: col (hidden) = lane&15, row (batch) = 4*(lane>>4) + e
 #pragma unroll
@@ -101,7 +113,14 @@ __global__ __launch_bounds__(256) void pose_epilogue_kernel(
   for (int o = 0; o < 8; ++o) po[o] = 0.f;
   for (int h = threadIdx.x; h < hidden; h += 256) {
     float s = 0.f;
-    for (int ks = 0; ks < nslice; ++ks) s += part[((long long)ks * B + b) * hidden + h];
+    for (int ks0 = 0; ks0 < nslice; ks0 += 8) {   // 8 independent loads in flight, summed in slice order
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = part[((long long)min(ks0 + i, nslice - 1) * B + b) * hidden + h];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (ks0 + i < nslice) s += t[i];
+    }
     s = fmaxf(s + b1[h], 0.f);
 #pragma unroll
     for (int o = 0; o < 8; ++o)
@@ -260,8 +279,8 @@ extern "C" int vpr_pose_head(const float* x, const float* W1, const float* b1, c
   if (!x || !W2 || !b2 || !out || B <= 0 || D <= 0 || hidden < 0 || n_out < 1) return VPR_ERR_INVALID_ARG;
   if (n_out > 8) return VPR_ERR_UNSUPPORTED;
   if (hidden == 0) {
-    hipLaunchKernelGGL(pose_linear_kernel, dim3(B), dim3(256), 0, stream, x, W2, b2, out, D, n_out, sincos_offset);
-    return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+    VPR_TRY_LAUNCH(launch_kernel(pose_linear_kernel, dim3(B), dim3(256), 0, stream, x, W2, b2, out, D, n_out, sincos_offset));
+    return VPR_OK;
   }
   if (!W1 || !b1 || !workspace) return VPR_ERR_INVALID_ARG;
   if ((D % 16) || (hidden % PH_HT)) return VPR_ERR_UNSUPPORTED;
@@ -271,23 +290,24 @@ extern "C" int vpr_pose_head(const float* x, const float* W1, const float* b1, c
   const int nsteps = D / 16;
   const int sps = (nsteps + ks - 1) / ks;
   float* part = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(pose_l1_partial_kernel, dim3(hidden / PH_HT, ks, (B + PH_BT - 1) / PH_BT), dim3(256), 0,
-                     stream, x, W1, part, B, D, hidden, sps);
-  hipLaunchKernelGGL(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
-                     hidden, n_out, sincos_offset);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(pose_l1_partial_kernel, dim3(hidden / PH_HT, ks, (B + PH_BT - 1) / PH_BT), dim3(256), 0,
+                     stream, x, W1, part, B, D, hidden, sps));
+  VPR_TRY_LAUNCH(launch_kernel(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
+                     hidden, n_out, sincos_offset));
+  return VPR_OK;
 }
 
 template <int VPL>
-static void launch_ln(const void* x, int bf16, int B, int T, const float* gamma, const float* beta, float eps,
+static int launch_ln(const void* x, int bf16, int B, int T, const float* gamma, const float* beta, float eps,
                       float* pooled, const float* Wh, const float* bh, int n_out, int so, float* out,
                       hipStream_t stream) {
   if (bf16)
-    hipLaunchKernelGGL((ln_meanpool_head_kernel<VPL, true>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
-                       eps, pooled, Wh, bh, n_out, so, out);
+    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, true>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
+                       eps, pooled, Wh, bh, n_out, so, out));
   else
-    hipLaunchKernelGGL((ln_meanpool_head_kernel<VPL, false>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
-                       eps, pooled, Wh, bh, n_out, so, out);
+    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, false>), dim3(B), dim3(256), 0, stream, x, T, gamma, beta,
+                       eps, pooled, Wh, bh, n_out, so, out));
+  return VPR_OK;
 }
 
 extern "C" int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, int H, const float* gamma,
@@ -300,11 +320,11 @@ extern "C" int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, 
   if (!pooled_out && !(Wh && n_out > 0)) return VPR_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(x) & 15) return VPR_ERR_UNSUPPORTED;
   switch (H) {
-    case 512:  launch_ln<8>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
-    case 768:  launch_ln<12>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
-    case 1024: launch_ln<16>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
-    case 1536: launch_ln<24>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream); break;
+    case 512: return launch_ln<8>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream);
+    case 768: return launch_ln<12>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream);
+    case 1024: return launch_ln<16>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream);
+    case 1536: return launch_ln<24>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream);
     default: return VPR_ERR_UNSUPPORTED;
   }
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  return VPR_OK;
 }

@@ -67,21 +67,27 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
   const float log_b = -log_nm;
 
   for (int it = 0; it < iters; ++it) {
-    // u_i = log_a_i - LSE_j(M_ij + v_j): wave per row
-    for (int i = wave; i <= SA_M; i += 4) {
-      float x[4];
-      float mx = -INFINITY;
+    // u_i = log_a_i - LSE_j(M_ij + v_j): one 16-lane row group per matrix row (16 rows of the
+    // matrix in flight per workgroup), 16 columns per lane, DPP-only reductions.
+    {
+      const int grp = tid >> 4, l16 = tid & 15;
+      for (int i0 = 0; i0 <= SA_M; i0 += 16) {
+        const int i = i0 + grp;
+        const int ic = i <= SA_M ? i : SA_M;      // clamp (EXEC stays full for the DPP steps)
+        float x[16];
+        float mx = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        x[c] = Mx[i * SA_LD + lane + 64 * c] + v[lane + 64 * c];
-        mx = fmaxf(mx, x[c]);
+        for (int c = 0; c < 16; ++c) {
+          x[c] = Mx[ic * SA_LD + l16 + 16 * c] + v[l16 + 16 * c];
+          mx = fmaxf(mx, x[c]);
+        }
+        mx = row16_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += expf(x[c] - mx);
+        s = row16_sum(s);
+        if (l16 == 0 && i <= SA_M) u[i] = (i == SA_M ? log_a_dust : log_a) - (mx + logf(s));
       }
-      mx = wave_max(mx);
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) s += expf(x[c] - mx);
-      s = wave_sum(s);
-      if (lane == 0) u[i] = (i == SA_M ? log_a_dust : log_a) - (mx + logf(s));
     }
     __syncthreads();
     // v_j = log_b - LSE_i(M_ij + u_i): thread per column
@@ -113,14 +119,27 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
   const int kh = lane >> 5, li = lane & 31;
-#pragma unroll 8
-  for (int s = 0; s < SA_N / 2; ++s) {
-    const int j = 2 * s + kh;
-    const float a = fb[j * SA_L + l0 + li];
-    const float p0 = Mx[li * SA_LD + j];
-    const float p1 = Mx[(32 + li) * SA_LD + j];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, p1, acc1, 0, 0, 0);
+  // F comes straight from L2/HBM (32 KB per wave, each value used once): 16 k-steps per chunk,
+  // the next chunk's 16 loads are in flight while the current chunk's 32 MFMAs run.
+  float a_cur[16], a_nxt[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a_cur[i] = fb[(2 * i + kh) * SA_L + l0 + li];
+#pragma unroll
+  for (int ch = 0; ch < SA_N / 32; ++ch) {
+    if (ch + 1 < SA_N / 32) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a_nxt[i] = fb[(2 * (16 * (ch + 1) + i) + kh) * SA_L + l0 + li];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = 2 * (16 * ch + i) + kh;
+      const float p0 = Mx[li * SA_LD + j];
+      const float p1 = Mx[(32 + li) * SA_LD + j];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], p0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], p1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a_cur[i] = a_nxt[i];
   }
 
   // ---- per-cluster L2 norm over l (F.normalize dim=1, eps 1e-12) ----
@@ -185,9 +204,9 @@ int launch_sinkhorn_aggregate(const float* scores, const float* feats, const flo
       return VPR_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(sinkhorn_aggregate_kernel, dim3(B), dim3(256), SINKHORN_LDS, stream,
-                     scores, feats, tokfeat, dustbin, iters, out_f32, out_bf16);
-  return hipGetLastError() == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+  VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel, dim3(B), dim3(256), SINKHORN_LDS, stream,
+                     scores, feats, tokfeat, dustbin, iters, out_f32, out_bf16));
+  return VPR_OK;
 }
 
 struct SaladPlan {

@@ -40,6 +40,28 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// All-reduce inside each 16-lane row with DPP only (no LDS traffic): xor 1, xor 2 as quad
+// permutes, then row_half_mirror and row_mirror (after the first two steps a quad holds one
+// value, so mirroring pairs the remaining groups).  Every lane ends with its row's result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f32<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f32<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_f32<0x140>(v));   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  return v;
+}
+
 // ---- LDS tile geometry -------------------------------------------------------------------
 // A tile row is 64 bf16 = 128 B = 8 chunks of 16 B.  Chunk c of row r is stored at physical
 // chunk c ^ ((r >> 1) & 7): with this XOR every ds_read_b128 lane group of both MFMA operand

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
 #include "../../include/vpr_amd.h"
 
 namespace vpr {
@@ -13,6 +15,24 @@ int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_gro
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
                               float* out_f32, uint16_t* out_bf16, hipStream_t stream);
+
+// Launch through hipLaunchKernel(), whose return value is THIS launch's status.  (The
+// hipGetLastError() idiom reads a per-thread sticky value that other libraries in the process —
+// e.g. hipBLASLt's kernel lookups inside PyTorch — leave set, so it cannot be trusted here.)
+template <typename... KArgs>
+inline int launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds_bytes,
+                         hipStream_t stream, typename std::common_type<KArgs>::type... args) {
+  void* ptrs[sizeof...(KArgs)] = {const_cast<void*>(static_cast<const void*>(&args))...};
+  const hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds_bytes, stream);
+  if (e != hipSuccess) {
+    fprintf(stderr, "libvpr_amd: kernel launch failed: %s (grid %u,%u,%u block %u lds %zu)\n",
+            hipGetErrorString(e), grid.x, grid.y, grid.z, block.x, lds_bytes);
+    return VPR_ERR_LAUNCH;
+  }
+  return VPR_OK;
+}
+
+#define VPR_TRY_LAUNCH(expr) do { const int vpr_st_ = (expr); if (vpr_st_ != VPR_OK) return vpr_st_; } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -1,0 +1,61 @@
+"""End-to-end inference step: images -> DINOv2 -> SALAD -> kNN vs. sharded gallery -> pose.
+
+This is the loop body of the reference's evaluation scripts
+(dinov2salad/dinov2salad_validation.py:78-88) with the north-star retrieval stage added
+ and without the per-batch host sync (.cpu().numpy() at :81): everything stays
+on the GPU, on one stream, until the caller asks for results.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from .modules import DinoV2Salad, FusedGeoPoseHead
+from .retrieval import ShardedGallery
+
+
+@dataclass
+class StepOutput:
+    descriptors: torch.Tensor          # [B, 8448] f32
+    topk_scores: torch.Tensor          # [B, k] f32
+    topk_indices: torch.Tensor         # [B, k] int32 (global gallery rows)
+    pose: torch.Tensor                 # [B, 4] f32: standardised (lat, lon), unit (sin, cos)
+
+
+class VPRGeoPosePipeline:
+    def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10):
+        self.extractor, self.head, self.gallery, self.k = extractor, head, gallery, k
+        self.knn_events = None     # optional list collecting (start, end) events of the score kernel
+
+    @torch.no_grad()
+    def step(self, images: torch.Tensor) -> StepOutput:
+        tokens = self.extractor.tokens(images)
+        desc, desc16 = self.extractor.aggregator(tokens, want_bf16=True)
+        g = self.gallery
+        q_all = g.gather_queries(desc16)
+        if self.knn_events is not None and g.world >= 1:
+            # same kernels as ShardedGallery.search, with HIP events around the score kernel
+            B = q_all.shape[0]
+            ws = ops.knn_workspace(B, g.rows.shape[0], q_all.shape[1], self.k, q_all.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.knn_scores(q_all, g.rows, ws)
+            e1.record()
+            self.knn_events.append((e0, e1))
+            v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base)
+            if g.world > 1:
+                import torch.distributed as dist
+                vs = torch.empty((g.world, B, self.k), dtype=v.dtype, device=v.device)
+                is_ = torch.empty((g.world, B, self.k), dtype=i.dtype, device=i.device)
+                dist.all_gather_into_tensor(vs, v, group=g.group)
+                dist.all_gather_into_tensor(is_, i, group=g.group)
+                v, i = ops.topk_merge(vs, is_)
+        else:
+            v, i = g.search(q_all, self.k)
+        b = desc.shape[0]
+        v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]
+        pose = self.head(desc)
+        return StepOutput(desc, v, i, pose)
