@@ -59,6 +59,35 @@ def test_knn_ties_prefer_lower_index(dev):
     assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
 
 
+def test_knn_all_equal_scores(dev):
+    """Degenerate input: a zero query scores 0 against every row -> the k lowest indices win.
+    (Worst case for the threshold select: every key ties on value.)"""
+    from vpr_amd import ops
+    N, D, k = 20000, 128, 10
+    g = _unit_rows(N, D, 21)
+    q = torch.zeros(2, D, dtype=torch.bfloat16)
+    q[1] = g[5]
+    v, i = ops.knn_topk(q.to(dev), g.to(dev), k)
+    v_ref, i_ref = oknn.knn_topk(q, g, k)
+    assert i.cpu()[0].tolist() == list(range(k)) and torch.equal(v.cpu()[0], torch.zeros(k))
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
+
+
+@pytest.mark.parametrize("descending", [True, False])
+def test_knn_monotone_scores(dev, descending):
+    """Scores sorted along the gallery index (all the winners inside one thread's stride / one
+    chunk): the adversarial layout for the per-thread-max threshold bound."""
+    from vpr_amd import ops
+    N, D, k = 30000, 64, 64
+    base = torch.nn.functional.normalize(torch.ones(1, D), dim=1)
+    scale = torch.linspace(1.0, 0.01, N) if descending else torch.linspace(0.01, 1.0, N)
+    g = (scale[:, None] * base).to(torch.bfloat16)
+    q = base.to(torch.bfloat16).repeat(3, 1)
+    v, i = ops.knn_topk(q.to(dev), g.to(dev), k)
+    v_ref, i_ref = oknn.knn_topk(q, g, k)
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
+
+
 def test_knn_scores_stage_close_to_exact(dev):
     """The MFMA score matrix (approximate stage) is within 2e-5 of the exact fp64 scores."""
     from vpr_amd import ops

@@ -9,9 +9,9 @@
 //                          64 FLOP per gallery byte.  THE dominant kernel (roofline: HBM).
 //   2. knn_select_kernel   per (query, 4096-score chunk): top-KP candidates by the MFMA score
 //                          (KP = oversampled k), repeated until one chunk is left -> [B][KP].
-//   3. knn_rescore_kernel  per query: EXACT rescoring of those KP rows (bf16 products
-//                          accumulated in f64, fixed order), final ordering by
-//                          (f32(score) desc, index asc), write top-k.
+//   3. knn_rescore_kernel  per (query, candidate): EXACT rescoring of the KP rows (bf16 products
+//                          accumulated in f64, fixed order);  knn_order_kernel: final ordering
+//                          by (f32(score) desc, index asc), write top-k.
 // The exact rescoring makes the result independent of MFMA accumulation order: indices are
 // bit-exact against oracle/knn.py as long as the true top-k lie inside the approximate top-KP
 // (MFMA f32 error ~1e-6 vs. the k-th..KP-th score gap).
@@ -23,7 +23,8 @@ namespace vpr {
 
 constexpr int KNN_TR = 144;        // gallery rows per tile (9 MFMA column blocks of 16)
 constexpr int KNN_QT = 64;         // queries per tile (4 waves x 16)
-constexpr int KNN_CHUNK = 4096;    // scores per select workgroup
+constexpr int KNN_CHUNK = 4096;    // candidates per workgroup of the register-held select levels
+constexpr int KNN_STREAM_CHUNK = 8192;   // scores per workgroup of the streaming level-0 select
 constexpr int KNN_WG_PER_CU = 3;
 
 __host__ __device__ inline int knn_kp(int k) {
@@ -167,27 +168,54 @@ struct SelectSmem {
 };
 
 // Block-wide top-kp of <= 4096 unique keys held 16 per thread, without a serial argmax loop:
-//   a. every thread publishes the max of its 16 keys;
-//   b. the kp-th largest thread-max T (found by rank counting) is a lower bound of the kp-th
+//   a. every thread (or, for kp <= 64, every group of 4 threads) publishes the max of its keys;
+//   b. the kp-th largest published max T (found by rank counting) is a lower bound of the kp-th
 //      largest key overall, so every top-kp key is >= T;
 //   c. keys >= T are appended to an LDS list (typically kp..2kp of them);
 //   d. each listed key counts the listed keys above it = its rank; ranks < kp go to outk[rank].
 // outk[0..kp) is complete (KEY_DEAD-padded) and visible to the whole block on return.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
 __device__ __forceinline__ void block_select(const unsigned long long (&keys)[16], int kp, SelectSmem& sm) {
   const int tid = threadIdx.x;
   unsigned long long best = KEY_DEAD;
 #pragma unroll
   for (int i = 0; i < 16; ++i) best = keys[i] > best ? keys[i] : best;
-  sm.tmax[tid] = best;
   if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
   if (tid < kp) sm.outk[tid] = KEY_DEAD;
-  __syncthreads();
-  int rank = 0;
-  for (int s = 0; s < 256; s += 2) {
-    const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
-    rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
+  if (kp <= 64) {
+    // 64 group maxes (4 adjacent lanes each, DPP quad permutes) are enough to bound kp <= 64
+    // keys, and ranking 64 values is 4x cheaper than ranking 256.
+    unsigned long long o = dpp_u64<0xB1>(best);
+    best = o > best ? o : best;
+    o = dpp_u64<0x4E>(best);
+    best = o > best ? o : best;
+    if ((tid & 3) == 0) sm.tmax[tid >> 2] = best;
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned long long mine = sm.tmax[tid];
+      int rank = 0;
+      for (int s = 0; s < 64; s += 2) {
+        const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
+        rank += (t2.x > mine ? 1 : 0) + (t2.y > mine ? 1 : 0);
+      }
+      if (rank == kp - 1 && mine != KEY_DEAD) sm.thr = mine;   // keys are unique: one writer
+    }
+  } else {
+    sm.tmax[tid] = best;
+    __syncthreads();
+    int rank = 0;
+    for (int s = 0; s < 256; s += 2) {
+      const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
+      rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
+    }
+    if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;
   }
-  if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;   // keys are unique: at most one writer
   __syncthreads();
   const unsigned long long T = sm.thr;
 #pragma unroll
@@ -252,69 +280,154 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
   }
 }
 
-// 3. rescore + order: grid (B), 1024 threads.  cand_idx [B][kp] are the approximate top-kp
-// gallery rows of the query (-1 = padding).  Wave w rescoring candidates w, w+16, ...: exact
-// score = sum of bf16*bf16 products in f64 (each product exact), fixed order (4 lane-strided
-// partial sums, combined, then a butterfly) -> independent of how the candidate was found.
-// Final order by (f32(exact) desc, index asc), rank by counting, top-k written.
-__global__ __launch_bounds__(1024) void knn_rescore_kernel(
-    const int32_t* __restrict__ cand_idx, const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G,
-    int D, int k, int kp, int index_base, float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
-  __shared__ float exact[128];
-  __shared__ int cidx[128];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)threadIdx.x < kp) cidx[threadIdx.x] = cand_idx[(long long)b * kp + threadIdx.x];
-  __syncthreads();
-  const uint16_t* qrow = Q + (long long)b * D;
-  const int nchunks = D >> 3;
-  for (int c = wave; c < kp; c += 16) {
-    const int id = cidx[c];
-    float s = -INFINITY;
-    if (id >= 0) {   // wave-uniform
-      const uint16_t* grow = G + (long long)id * D;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int ch0 = lane; ch0 < nchunks; ch0 += 256) {
-        s16x8 qa[4], ga[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ch = ch0 + 64 * u;
-          const int chc = ch < nchunks ? ch : ch0;          // clamp: always a valid address
-          qa[u] = *reinterpret_cast<const s16x8*>(qrow + chc * 8);
-          ga[u] = *reinterpret_cast<const s16x8*>(grow + chc * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (ch0 + 64 * u < nchunks) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              acc[u] = fma((double)bf16_bits_to_f32((uint16_t)qa[u][j]),
-                           (double)bf16_bits_to_f32((uint16_t)ga[u][j]), acc[u]);
-          }
-        }
+// 2a. level-0 select straight from the score matrix: grid (chunks, B), chunk = `ch` scores
+// (multiple of 1024, <= 8192).  Two streaming passes instead of holding the chunk in registers:
+//   pass 1  every thread finds the max KEY (value, then lower index) of its strided elements;
+//   rank    the kp-th largest of the 256 thread maxes, T, bounds the kp-th largest key of the
+//           chunk from below (keys are unique, so at most (ch/256)*(kp-1)+1 <= 4096 keys are >= T
+//           whatever the data — ties, sorted input, all-equal scores);
+//   pass 2  re-read the chunk (L2-hot) and append keys >= T to an LDS list (typically ~kp);
+//   order   each listed key counts the listed keys above it = its rank; ranks < kp are written.
+__global__ __launch_bounds__(256) void knn_select_stream_kernel(
+    const float* __restrict__ S, int N, long long ldS, int ch,
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk) {
+  __shared__ SelectSmem sm;
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* v = S + (long long)b * ldS;
+  const int base = c * ch;
+  const int len = min(ch, N - base);          // >= 1
+  unsigned long long best = KEY_DEAD;
+  for (int p = tid * 4; p < len; p += 1024) {
+    if (p + 4 <= len) {
+      const float4 q = *reinterpret_cast<const float4*>(v + base + p);
+      unsigned long long k0 = make_key(q.x, base + p), k1 = make_key(q.y, base + p + 1);
+      unsigned long long k2 = make_key(q.z, base + p + 2), k3 = make_key(q.w, base + p + 3);
+      k0 = k1 > k0 ? k1 : k0;
+      k2 = k3 > k2 ? k3 : k2;
+      k0 = k2 > k0 ? k2 : k0;
+      best = k0 > best ? k0 : best;
+    } else {
+      for (int e = p; e < len; ++e) {
+        const unsigned long long k = make_key(v[base + e], base + e);
+        best = k > best ? k : best;
       }
-      const double tot = wave_sum_f64((acc[0] + acc[1]) + (acc[2] + acc[3]));
-      s = (float)tot;
     }
-    if (lane == 0) exact[c] = s;
+  }
+  sm.tmax[tid] = best;
+  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
+  if (tid < kp) sm.outk[tid] = KEY_DEAD;
+  __syncthreads();
+  {
+    int rank = 0;
+    for (int s = 0; s < 256; s += 2) {
+      const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
+      rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
+    }
+    if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;   // unique keys: one writer
   }
   __syncthreads();
-  if ((int)threadIdx.x < kp) {
-    const int i = threadIdx.x;
-    const int id = cidx[i];
-    int rank;
-    if (id < 0) {
-      rank = i;    // padding sits behind every real entry already (select output is ordered)
+  const unsigned long long T = sm.thr;
+  for (int p = tid * 4; p < len; p += 1024) {
+    if (p + 4 <= len) {
+      const float4 q = *reinterpret_cast<const float4*>(v + base + p);
+      const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned long long k = make_key(qq[e], base + p + e);
+        if (k >= T) sm.cand[atomicAdd(&sm.cnt, 1)] = k;
+      }
     } else {
-      const unsigned long long mine = make_key(exact[i], id);
-      rank = 0;
-      for (int j = 0; j < kp; ++j) {
-        const int jd = cidx[j];
-        rank += (jd >= 0 && make_key(exact[j], jd) > mine) ? 1 : 0;
+      for (int e = p; e < len; ++e) {
+        const unsigned long long k = make_key(v[base + e], base + e);
+        if (k >= T) sm.cand[atomicAdd(&sm.cnt, 1)] = k;
       }
     }
+  }
+  __syncthreads();
+  const int cn = sm.cnt;
+  for (int ci = tid; ci < cn; ci += 256) {
+    const unsigned long long mine = sm.cand[ci];
+    int r = 0;
+    for (int cj = 0; cj < cn; ++cj) r += sm.cand[cj] > mine ? 1 : 0;
+    if (r < kp) sm.outk[r] = mine;
+  }
+  __syncthreads();
+  if (tid < kp) {
+    const unsigned long long k = sm.outk[tid];
+    const long long o = ((long long)b * nchunk + c) * kp + tid;
+    out_val[o] = k == KEY_DEAD ? -INFINITY : key_val(k);
+    out_idx[o] = k == KEY_DEAD ? -1 : key_idx(k);
+  }
+}
+
+// 3a. exact rescoring: grid (kp, B), one workgroup per (candidate, query).  cand_idx [B][kp] are
+// the approximate top-kp gallery rows (-1 = padding).  exact score = sum of bf16*bf16 products
+// in f64 (each product is exact), in a fixed order (thread-strided 16-B chunks in sequence, wave
+// butterfly, then the 4 wave sums) -> independent of how the candidate was found.  All of a
+// thread's loads are issued before the first FMA: one trip to HBM per row.
+constexpr int RS_U = 6;   // 16-B chunks per thread per trip (256 threads x 6 x 8 = 12288 elements)
+__global__ __launch_bounds__(256) void knn_rescore_kernel(
+    const int32_t* __restrict__ cand_idx, const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G,
+    int D, int kp, float* __restrict__ exact) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int id = cand_idx[(long long)b * kp + c];
+  if (id < 0) {   // uniform
+    if (threadIdx.x == 0) exact[(long long)b * kp + c] = -INFINITY;
+    return;
+  }
+  const uint16_t* qrow = Q + (long long)b * D;
+  const uint16_t* grow = G + (long long)id * D;
+  const int nchunks = D >> 3;
+  double acc = 0.0;
+  for (int ch0 = threadIdx.x; ch0 < nchunks; ch0 += 256 * RS_U) {
+    s16x8 qa[RS_U], ga[RS_U];
+#pragma unroll
+    for (int u = 0; u < RS_U; ++u) {
+      const int ch = ch0 + 256 * u;
+      const int chc = ch < nchunks ? ch : ch0;          // clamp: always a valid address
+      qa[u] = *reinterpret_cast<const s16x8*>(qrow + chc * 8);
+      ga[u] = *reinterpret_cast<const s16x8*>(grow + chc * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < RS_U; ++u) {
+      if (ch0 + 256 * u < nchunks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc = fma((double)bf16_bits_to_f32((uint16_t)qa[u][j]), (double)bf16_bits_to_f32((uint16_t)ga[u][j]), acc);
+      }
+    }
+  }
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) exact[(long long)b * kp + c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// 3b. final order: grid (B), 128 threads.  Rank the kp rescored candidates by
+// (f32(exact) desc, index asc) by counting; write the top-k with global indices.
+__global__ __launch_bounds__(128) void knn_order_kernel(
+    const int32_t* __restrict__ cand_idx, const float* __restrict__ exact, int k, int kp, int index_base,
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  __shared__ unsigned long long key[128];
+  const int b = blockIdx.x, i = threadIdx.x;
+  int id = -1;
+  unsigned long long mine = KEY_DEAD;
+  if (i < kp) {
+    id = cand_idx[(long long)b * kp + i];
+    if (id >= 0) mine = make_key(exact[(long long)b * kp + i], id);
+  }
+  key[i] = mine;
+  __syncthreads();
+  if (i < kp) {
+    int rank = 0;
+    if (id < 0) {
+      rank = i;     // padding already sits behind every real entry (select output is ordered)
+    } else {
+      for (int j = 0; j < kp; ++j) rank += key[j] > mine ? 1 : 0;
+    }
     if (rank < k) {
-      out_val[(long long)b * k + rank] = id < 0 ? -INFINITY : exact[i];
+      out_val[(long long)b * k + rank] = id < 0 ? -INFINITY : key_val(mine);
       out_idx[(long long)b * k + rank] = id < 0 ? -1 : id + index_base;
     }
   }
@@ -350,7 +463,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct KnnPlan {
-  int Bpad, ldS, kp;
+  int Bpad, ldS, kp, ch0;
   int nlevel;            // number of select levels before the final kernel
   int L[4], nchunk[4];   // input length / chunk count per level
   size_t off_S, off_cv[2], off_ci[2], total;
@@ -361,14 +474,17 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
   p->Bpad = (B + KNN_QT - 1) / KNN_QT * KNN_QT;
   p->ldS = (N + 63) / 64 * 64;
   p->kp = knn_kp(k);
-  // select levels: each turns L entries per query into ceil(L/4096)*kp; the last level has one
-  // chunk, so its output is the [B][kp] candidate list the rescoring kernel takes.
+  // select levels: level 0 streams the score matrix in chunks of ch0 (<= 8192) scores, later
+  // levels hold <= 4096 candidates per workgroup in registers; each level turns L entries per
+  // query into nchunk*kp, and the last level has one chunk -> the [B][kp] list to rescore.
+  p->ch0 = N > KNN_STREAM_CHUNK ? KNN_STREAM_CHUNK : (N + 1023) / 1024 * 1024;
   p->nlevel = 0;
   int L = N;
   for (;;) {
     if (p->nlevel >= 4) return false;
+    const int chunk = p->nlevel == 0 ? p->ch0 : KNN_CHUNK;
     p->L[p->nlevel] = L;
-    p->nchunk[p->nlevel] = (L + KNN_CHUNK - 1) / KNN_CHUNK;
+    p->nchunk[p->nlevel] = (L + chunk - 1) / chunk;
     L = p->nchunk[p->nlevel] * p->kp;
     ++p->nlevel;
     if (p->nchunk[p->nlevel - 1] == 1) break;
@@ -430,14 +546,21 @@ int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k,
   for (int lev = 0; lev < p.nlevel; ++lev) {
     float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
-    VPR_TRY_LAUNCH(launch_kernel(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
-                       cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]));
+    if (lev == 0)
+      VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel, dim3(p.nchunk[0], B), dim3(256), 0, stream,
+                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0]));
+    else
+      VPR_TRY_LAUNCH(launch_kernel(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
+                                   cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]));
     cur_v = ov; cur_i = oi;
     L = p.nchunk[lev] * p.kp;
     ld = L;
   }
-  VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel, dim3(B), dim3(1024), 0, stream,
-                     cur_i, q, g, D, k, p.kp, index_base, out_val, out_idx));
+  // exact scores go into the (now free) other candidate-value buffer
+  float* exact = reinterpret_cast<float*>(w + p.off_cv[p.nlevel & 1]);
+  VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel, dim3(p.kp, B), dim3(256), 0, stream, cur_i, q, g, D, p.kp, exact));
+  VPR_TRY_LAUNCH(launch_kernel(knn_order_kernel, dim3(B), dim3(128), 0, stream, cur_i, exact, k, p.kp,
+                               index_base, out_val, out_idx));
   return VPR_OK;
 }
 
