@@ -1,0 +1,98 @@
+"""GPU: the HIP heads (through the product modules, i.e. through the C ABI) against golden vectors
+produced by the reference's own classes (tests/golden/make_golden.py).  Tolerance 1e-4 (north
+star) on standardised outputs; observed errors are ~1e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from test_oracle_golden import G, regen_head
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def test_dinov2_regression_model_reproduces_reference_head(dev):
+    from vpr_amd import modules
+    meta = json.load(open(os.path.join(G, "head_dinov2salad.json")))
+    reg, x = regen_head(meta)
+    model = modules.DINOv2RegressionModel(nn.Identity())
+    model.load_state_dict({"regressor." + k: v for k, v in reg.state_dict().items()})
+    model = model.to(dev).eval()
+    out = model(x.to(dev)).cpu().double()
+    ref = torch.tensor(meta["outputs"], dtype=torch.float64)
+    err = (out - ref).abs().max().item()
+    print("head vs reference class:", err)
+    assert err < TOL
+    # de-normalised with the campus scaler in fp64: still within 1e-4 * scale of the reference output
+    from vpr_amd import postproc
+    sc = postproc.LatLonScaler.campus()
+    assert np.abs(sc.inverse_transform(out.numpy()) - sc.inverse_transform(ref.numpy())).max() < TOL * sc.scale_.max()
+
+
+def test_swin_pooler_and_heads_reproduce_hf(dev):
+    from vpr_amd import ops
+    z = np.load(os.path.join(G, "swin_pool_head.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    pooled, out = ops.ln_meanpool_head(t("pre_ln"), t("gamma"), t("beta"), float(z["eps"]), t("W"), t("b"))
+    assert (pooled.cpu() - torch.from_numpy(z["pooled"])).abs().max().item() < 2e-5
+    assert (out.cpu() - torch.from_numpy(z["out"])).abs().max().item() < TOL
+    _, out_u = ops.ln_meanpool_head(t("pre_ln"), t("gamma"), t("beta"), float(z["eps"]), t("W"), t("b"), 0)
+    assert (out_u.cpu() - torch.from_numpy(z["out_unit"])).abs().max().item() < TOL
+
+
+def test_swin_models_end_to_end_match_hf_on_gpu(dev):
+    """SwinRegressionModel / SwinSinCosRegressionModel / SwinMLPRegressionModel with a random-init
+    HF SwinModel(SwinConfig()) backbone (architecture only): fused HIP pooler+head vs HF's own
+    pooler_output + torch Linear on the same GPU (BASELINE config 1 plumbing, batch 8)."""
+    from transformers import SwinConfig, SwinModel
+    from vpr_amd import modules
+    torch.manual_seed(0)
+    bb = SwinModel(SwinConfig()).to(dev).eval()
+    x = torch.randn(8, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        pooled_ref = bb(pixel_values=x).pooler_output
+    lin = modules.SwinRegressionModel(bb).to(dev).eval()
+    with torch.no_grad():
+        ref = lin.regressor(pooled_ref)
+    assert (lin(x) - ref).abs().max().item() < TOL
+    sc = modules.SwinSinCosRegressionModel(bb).to(dev).eval()
+    sc.regressor.load_state_dict(lin.regressor.state_dict())
+    ref_u = torch.nn.functional.normalize(ref, dim=1, p=2, eps=1e-6)
+    out_u = sc(x)
+    assert (out_u - ref_u).abs().max().item() < TOL
+    assert (out_u.pow(2).sum(1) - 1).abs().max().item() < 1e-5
+    mlp = modules.SwinMLPRegressionModel(bb).to(dev).eval()
+    with torch.no_grad():
+        ref_m = mlp.regressor(pooled_ref)
+    assert (mlp(x) - ref_m).abs().max().item() < TOL
+
+
+def test_pipeline_step_shapes_and_consistency(dev):
+    """One end-to-end step on a small backbone; retrieval of a planted gallery row; pose halves
+    equal the separate heads."""
+    from vpr_amd import ops
+    from vpr_amd.modules import DinoV2Salad, FusedGeoPoseHead
+    from vpr_amd.pipeline import VPRGeoPosePipeline
+    from vpr_amd.retrieval import ShardedGallery
+    torch.manual_seed(1)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    pos = nn.Sequential(nn.Linear(8448, 512), nn.ReLU(), nn.Linear(512, 2)).to(dev)
+    ang = nn.Sequential(nn.Linear(8448, 128), nn.ReLU(), nn.Linear(128, 2)).to(dev)
+    head = FusedGeoPoseHead(pos, ang)
+    images = torch.randn(4, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    desc = ext(images)
+    gal = torch.nn.functional.normalize(torch.randn(700, 8448, device=dev), dim=1)
+    gal[123] = desc[2]                     # plant query 2's own descriptor
+    pipe = VPRGeoPosePipeline(ext, head, ShardedGallery(ops.f32_to_bf16(gal), 700), k=5)
+    out = pipe.step(images)
+    assert out.descriptors.shape == (4, 8448) and out.topk_indices.shape == (4, 5) and out.pose.shape == (4, 4)
+    assert torch.equal(out.descriptors, desc)
+    assert out.topk_indices[2, 0].item() == 123 and out.topk_scores[2, 0].item() > 0.99
+    assert (out.pose[:, 2:].pow(2).sum(1) - 1).abs().max().item() < 1e-5
+    sep = ops.pose_head(desc, pos[0].weight, pos[0].bias, pos[2].weight, pos[2].bias)
+    # block-diagonal fusion adds exact zeros; only the split-K partition (summation order) differs
+    assert (out.pose[:, :2] - sep).abs().max().item() < 1e-6

@@ -1,0 +1,123 @@
+"""CPU: host-side mirror of the reference interface (state-dict keys, checkpoint forms, fused
+head packing) and the sharded-retrieval plumbing over gloo with world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from oracle import heads as oheads
+from oracle import knn as oknn
+
+
+def test_state_dict_keys_match_reference():
+    from vpr_amd import modules
+    m = modules.DINOv2RegressionModel(nn.Identity())
+    assert [k for k in m.state_dict()] == ["regressor.0.weight", "regressor.0.bias", "regressor.2.weight", "regressor.2.bias"]
+    assert tuple(m.regressor[0].weight.shape) == (512, 8448) and tuple(m.regressor[2].weight.shape) == (2, 512)
+
+    class FakeSwin(nn.Module):
+        def __init__(self, h):
+            super().__init__()
+            self.config = type("C", (), {"hidden_size": h})()
+            self.layernorm = nn.LayerNorm(h)
+    s = modules.SwinRegressionModel(FakeSwin(768))
+    assert {"regressor.weight", "regressor.bias"} <= set(s.state_dict())
+    b = modules.SwinMLPRegressionModel(FakeSwin(1024))
+    assert {"regressor.0.weight", "regressor.0.bias", "regressor.3.weight", "regressor.3.bias"} <= set(b.state_dict())
+    assert tuple(b.regressor[0].weight.shape) == (512, 1024)
+    agg = modules.SaladAggregator(768)
+    keys = set(agg.state_dict())
+    for k in ("score.0.weight", "score.3.weight", "cluster_features.0.weight", "cluster_features.3.bias",
+              "token_features.0.weight", "token_features.2.bias", "dust_bin"):
+        assert k in keys
+    assert tuple(agg.score[0].weight.shape) == (512, 768, 1, 1) and tuple(agg.cluster_features[3].weight.shape) == (128, 512, 1, 1)
+
+
+def test_checkpoint_forms(tmp_path):
+    from vpr_amd import modules
+    src = modules.DINOv2RegressionModel(nn.Identity())
+    a, b = tmp_path / "wrapped.pth", tmp_path / "bare.pth"
+    torch.save({"epoch": 3, "model_state_dict": src.state_dict(), "loss": 0.1}, a)    # dinov2salad_finetuning.py:130-135
+    torch.save(src.state_dict(), b)                                                   # swin_attempt_2.py:255
+    for path in (a, b):
+        dst = modules.load_reference_checkpoint(modules.DINOv2RegressionModel(nn.Identity()), str(path))
+        assert torch.equal(dst.regressor[0].weight, src.regressor[0].weight)
+
+
+def test_fused_head_packing_is_block_diagonal():
+    from vpr_amd import modules
+    torch.manual_seed(0)
+    pos = nn.Sequential(nn.Linear(64, 32), nn.ReLU(), nn.Linear(32, 2))
+    ang = nn.Sequential(nn.Linear(64, 16), nn.ReLU(), nn.Dropout(0.0), nn.Linear(16, 2))
+    W1, b1, W2, b2 = modules.FusedGeoPoseHead(pos, ang).pack()
+    assert W1.shape == (48, 64) and W2.shape == (4, 48)
+    assert torch.count_nonzero(W2[:2, 32:]) == 0 and torch.count_nonzero(W2[2:, :32]) == 0
+    x = torch.randn(5, 64)
+    fused = oheads.mlp_head(x, W1, b1, W2, b2, 2, dtype=torch.float32)
+    with torch.no_grad():
+        sep = torch.cat([pos(x), torch.nn.functional.normalize(ang(x), dim=1, eps=1e-6)], 1)
+    assert torch.allclose(fused, sep, atol=1e-6)
+
+
+def test_shard_bounds_cover_gallery():
+    from vpr_amd.retrieval import shard_bounds
+    for N, R in ((100000, 8), (12501, 7), (5, 8)):
+        spans = [shard_bounds(N, r, R) for r in range(R)]
+        assert spans[0][0] == 0 and spans[-1][1] == N
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(R - 1))
+
+
+class OracleEngine:
+    """Test double for the HIP engine: same contract, CPU oracle arithmetic."""
+    def local_topk(self, q, gallery, k, index_base):
+        return oknn.knn_topk(q, gallery, k, index_base)
+
+    def merge(self, vals, idxs):
+        return oknn.topk_merge(vals, idxs)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, D, B, k, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vpr_amd.retrieval import ShardedGallery, shard_bounds
+    g = torch.Generator().manual_seed(0)
+    gal = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1).to(torch.bfloat16)
+    q_all = torch.nn.functional.normalize(torch.randn(world * B, D, generator=g), dim=1).to(torch.bfloat16)
+    lo, hi = shard_bounds(N, rank, world)
+    sg = ShardedGallery(gal[lo:hi].contiguous(), N, rank, world, engine=OracleEngine())
+    v, i = sg.search_local_queries(q_all[rank * B:(rank + 1) * B].contiguous(), k)
+    v_ref, i_ref = oknn.knn_topk(q_all, gal, k)
+    ok = torch.equal(i, i_ref[rank * B:(rank + 1) * B]) and torch.equal(v, v_ref[rank * B:(rank + 1) * B])
+    gathered = sg.gather_queries(q_all[rank * B:(rank + 1) * B].contiguous())
+    ok = ok and torch.equal(gathered, q_all)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_retrieval_gloo_world2():
+    world = 2
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), 301, 64, 3, 5, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_recall_at_k():
+    from vpr_amd import postproc
+    idx = np.array([[3, 9], [4, 1], [7, 7]])
+    assert postproc.recall_at_k(idx[:, :1], [3, 1, 7]) == pytest.approx(2 / 3)
+    assert postproc.recall_at_k(idx, [3, 1, 7]) == 1.0
+    assert postproc.recall_at_k(idx, [[5, 9], [0], [7]]) == pytest.approx(2 / 3)

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library builds, loads, exports every symbol include/vpr_amd.h declares, and
+rejects bad arguments before touching a device (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import vpr_amd
+    vpr_amd.build_library()          # hipcc cross-compiles gfx950 without a GPU
+    from vpr_amd import _lib
+    return _lib.lib()
+
+
+def test_header_and_binding_agree(lib):
+    from vpr_amd import _lib
+    header = open(os.path.join(ROOT, "include", "vpr_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(vpr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vpr_status", "vpr_salad_weights"}
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libvpr_amd.so"
+    assert lib.vpr_abi_version() == _lib.ABI_VERSION
+
+
+def test_status_strings(lib):
+    assert lib.vpr_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, 17):
+        assert len(lib.vpr_status_string(code)) > 0
+
+
+def test_workspace_queries(lib):
+    assert lib.vpr_knn_workspace_bytes(64, 100000, 8448, 10) >= 64 * 100000 * 4
+    assert lib.vpr_knn_workspace_bytes(64, 1000, 8447, 10) == 0        # D % 64 != 0
+    assert lib.vpr_knn_workspace_bytes(64, 1000, 8448, 65) == 0        # k > 64
+    assert lib.vpr_knn_workspace_bytes(0, 1000, 8448, 10) == 0
+    assert lib.vpr_salad_workspace_bytes(64, 256, 1024, 64, 128, 256, 512) >= 64 * 256 * 1024 * 2
+    assert lib.vpr_pose_head_workspace_bytes(64, 8448, 512, 4) > 0
+    assert lib.vpr_pose_head_workspace_bytes(64, 768, 0, 2) > 0
+
+
+def test_invalid_arguments_are_rejected_without_a_device(lib):
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.vpr_knn_topk(null, null, 1, 1, 64, 1, 0, null, null, null, 0, null) in (-1, -3)
+    assert lib.vpr_knn_topk(p, p, 1, 10, 65, 1, 0, p, p, p, 4096, null) == -2           # D % 64
+    assert lib.vpr_knn_topk(p, p, 1, 10, 64, 1, 0, p, p, p, 16, null) == -3             # workspace too small
+    assert lib.vpr_topk_merge(null, null, 2, 1, 1, null, null, null) == -1
+    assert lib.vpr_topk_merge(p, p, 5000, 1, 1, p, p, null) == -2
+    assert lib.vpr_pose_head(null, null, null, null, null, null, 1, 64, 32, 2, -1, null, 0, null) == -1
+    assert lib.vpr_pose_head(p, p, p, p, p, p, 1, 65, 32, 2, -1, p, 4096, null) == -2    # D % 16
+    assert lib.vpr_pose_head(p, p, p, p, p, p, 1, 64, 32, 9, -1, p, 4096, null) == -2    # n_out > 8
+    assert lib.vpr_ln_meanpool_head(p, 0, 1, 4, 100, p, p, 1e-5, p, null, null, 0, -1, null, null) == -2   # H unsupported
+    assert lib.vpr_gemm_nt_bf16(p, 64, 0, 0, p, 64, null, 0, p, 8, 0, 8, 8, 60, null) == -2   # K % 64
+    assert lib.vpr_salad_sinkhorn_aggregate(p, p, p, 1, 100, 64, 128, 256, 1.0, 3, p, null, null) == -2
+    assert lib.vpr_f32_to_bf16(null, null, 4, null) == -1
+    assert lib.vpr_f32_to_bf16(p, p, 0, null) == 0
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from vpr_amd import ops
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.knn_topk(torch.zeros(1, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16), 1)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.pose_head(torch.zeros(1, 64), None, None, torch.zeros(2, 64), torch.zeros(2))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from vpr_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "library_path", lambda: str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_lds_swizzle_is_conflict_free():
+    """Host re-derivation of vpr_common.cuh::tile_off for every ds_read_b128 lane group of both
+    MFMA operand maps (bank = (addr/4) % 64; a 16-lane group must hit 16 distinct 16-B slots)."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+              [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[x + 32 for x in g] for g in groups]
+    off = lambda row, chunk: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+    for kk in (0, 1):                                   # 16x16x32: row = lane&15, chunk = lane>>4 (+4)
+        for g in groups:
+            slots = {(off(l & 15, (l >> 4) + 4 * kk) // 16) % 16 for l in g}
+            assert len(slots) == 16
+    for s in range(4):                                  # 32x32x16: row = lane&31, chunk = lane>>5 (+2s)
+        for g in groups:
+            slots = {(off(l & 31, (l >> 5) + 2 * s) // 16) % 16 for l in g}
+            assert len(slots) == 16
+    # the staging side writes physical slot (row, p) with logical chunk p ^ swz(row): a bijection per row
+    for row in range(16):
+        assert sorted((p ^ ((row >> 1) & 7)) for p in range(8)) == list(range(8))

@@ -1,0 +1,90 @@
+"""CPU: closed-form known answers that pin the SALAD and kNN oracles (SURVEY.md §8c — both are
+'parity unpinned' by the reference, so these identities are what holds them in place)."""
+import math
+
+import torch
+
+from oracle import knn as oknn
+from oracle import salad as osalad
+
+
+def test_sinkhorn_column_marginals_exact():
+    """(1) the v-update is the last half-step, so every column of P (dustbin included) sums to 1."""
+    g = torch.Generator().manual_seed(0)
+    S = torch.randn(3, 64, 256, generator=g, dtype=torch.float64) * 3
+    P = osalad.matching_probs(S, dustbin=0.7, num_iters=3)
+    assert P.shape == (3, 65, 256)
+    assert (P.sum(1) - 1).abs().max().item() < 1e-12
+    # row sums only approximately 1 / (n-m) after 3 iterations
+    assert (P[:, :64].sum(2) - 1).abs().max().item() < 0.5
+    assert (P[:, 64].sum(1) - 192).abs().max().item() < 40
+
+
+def test_uniform_scores_closed_form():
+    """(2) all scores == dustbin: P = 1/n for clusters, (n-m)/n for the dustbin, after 1 iteration."""
+    S = torch.full((1, 64, 256), 1.5, dtype=torch.float64)
+    for iters in (1, 3):
+        P = osalad.matching_probs(S, dustbin=1.5, num_iters=iters)
+        assert (P[:, :64] - 1 / 256).abs().max().item() < 1e-14
+        assert (P[:, 64] - 192 / 256).abs().max().item() < 1e-14
+
+
+def test_descriptor_norm_shares_and_invariances():
+    g = torch.Generator().manual_seed(1)
+    scores = torch.randn(2, 256, 64, generator=g)
+    feats = torch.randn(2, 256, 128, generator=g)
+    tok = torch.randn(2, 256, generator=g)
+    out = osalad.sinkhorn_aggregate(scores, feats, tok, 1.0, 3)
+    assert out.shape == (2, 8448)
+    assert (out.pow(2).sum(1) - 1).abs().max().item() < 1e-12                      # (3)
+    assert (out[:, :256].pow(2).sum(1) - 1 / 65).abs().max().item() < 1e-12
+    assert (out[:, 256:].reshape(2, 128, 64).pow(2).sum(1) - 1 / 65).abs().max().item() < 1e-12
+    perm = torch.randperm(256, generator=g)                                         # (4)
+    assert (osalad.sinkhorn_aggregate(scores[:, perm], feats[:, perm], tok, 1.0, 3) - out).abs().max().item() < 1e-12
+    assert (osalad.sinkhorn_aggregate(scores.double() + 2.5, feats, tok, 3.5, 3) - out).abs().max().item() < 1e-12   # (5)
+    out32 = osalad.sinkhorn_aggregate(scores, feats, tok, 1.0, 3, dtype=torch.float32)                       # (6)
+    assert (out32.double() - out).abs().max().item() < 2e-6
+    # flatten order is l-major: index 256 + l*64 + m
+    V = out[0, 256:].reshape(128, 64)
+    assert torch.allclose(V[:, 5].norm(), torch.tensor(1 / math.sqrt(65.0), dtype=torch.float64))
+
+
+def test_salad_mlps_quantisation_points():
+    g = torch.Generator().manual_seed(2)
+    tokens = torch.randn(1, 257, 128, generator=g).to(torch.bfloat16)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.05
+    w = dict(w1_sc=r(1024, 128).bfloat16(), b1_sc=r(1024), w2_s=r(64, 512).bfloat16(), b2_s=r(64),
+             w2_c=r(128, 512).bfloat16(), b2_c=r(128), w1_t=r(512, 128).bfloat16(), b1_t=r(512),
+             w2_t=r(256, 512).bfloat16(), b2_t=r(256))
+    a = osalad.salad_aggregate(tokens, w, 1.0, 3, quantize=True)
+    b = osalad.salad_aggregate(tokens, w, 1.0, 3, quantize=False)
+    assert a.shape == (1, 8448) and 0 < (a - b).abs().max().item() < 1e-3
+
+
+def test_knn_oracle_against_python_loop():
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(3, 64, generator=g).to(torch.bfloat16)
+    gal = torch.randn(40, 64, generator=g).to(torch.bfloat16)
+    gal[17] = gal[4]                                      # a tie
+    v, i = oknn.knn_topk(q, gal, 6, index_base=100)
+    for b in range(3):
+        scores = []
+        for n in range(40):
+            s = sum(float(q[b, d]) * float(gal[n, d]) for d in range(64))   # python floats = fp64
+            scores.append((-float(torch.tensor(s, dtype=torch.float64).to(torch.float32)), n))
+        scores.sort()
+        assert [100 + n for _, n in scores[:6]] == i[b].tolist()
+        assert [-s for s, _ in scores[:6]] == v[b].tolist()
+
+
+def test_knn_merge_equals_unsharded_and_pads():
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(5, 32, generator=g).to(torch.bfloat16)
+    gal = torch.randn(90, 32, generator=g).to(torch.bfloat16)
+    v_all, i_all = oknn.knn_topk(q, gal, 7)
+    parts = [oknn.knn_topk(q, gal[lo:hi], 7, lo) for lo, hi in ((0, 30), (30, 33), (33, 90))]   # middle shard has < k rows
+    vm, im = oknn.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(im, i_all) and torch.equal(vm, v_all)
+    v, i = oknn.knn_topk(q, gal[:3], 5)
+    assert (i[:, 3:] == -1).all() and torch.isinf(v[:, 3:]).all()
+    assert oknn.recall_at_1(i_all[:, 0], i_all[:, 0]) == 1.0

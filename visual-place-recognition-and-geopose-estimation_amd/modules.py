@@ -156,8 +156,9 @@ class SwinMLPRegressionModel(nn.Module):
 
 class FusedGeoPoseHead(nn.Module):
     """(lat, lon, sin, cos) in ONE kernel call from two independent MLP heads on the same features:
-    hidden layers are row-concatenated and the output layer is block-diagonal, so each half is
-    bit-for-bit its own head (the zero blocks add exact zeros).  pos: DINOv2RegressionModel
+    hidden layers are row-concatenated and the output layer is block-diagonal, so each half is its
+    own head (the zero blocks add exact zeros; only the f32 summation order of the split-K
+    partition can differ from a separate call, ~1e-7).  pos: DINOv2RegressionModel
     .regressor; ang: Linear-ReLU-Linear(…,2) giving [sin, cos], unit-normalised if `normalize`."""
 
     def __init__(self, pos: nn.Sequential, ang: nn.Sequential, normalize: bool = True):

@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .modules import DinoV2Salad, FusedGeoPoseHead
-from .retrieval import ShardedGallery
+from .retrieval import ShardedGallery, all_gather_topk
 
 
 @dataclass
@@ -47,11 +47,7 @@ class VPRGeoPosePipeline:
             self.knn_events.append((e0, e1))
             v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base)
             if g.world > 1:
-                import torch.distributed as dist
-                vs = torch.empty((g.world, B, self.k), dtype=v.dtype, device=v.device)
-                is_ = torch.empty((g.world, B, self.k), dtype=i.dtype, device=i.device)
-                dist.all_gather_into_tensor(vs, v, group=g.group)
-                dist.all_gather_into_tensor(is_, i, group=g.group)
+                vs, is_ = all_gather_topk(v, i, g.world, g.group)
                 v, i = ops.topk_merge(vs, is_)
         else:
             v, i = g.search(q_all, self.k)

@@ -34,6 +34,16 @@ class HipEngine:
         return ops.topk_merge(vals, idxs)
 
 
+def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
+    """Per-shard (vals, idx) [B,k] -> [world, B, k] on every rank (two small all-gathers)."""
+    B, k = v.shape
+    vs = torch.empty((world * B, k), dtype=v.dtype, device=v.device)      # concatenated along dim 0:
+    is_ = torch.empty((world * B, k), dtype=i.dtype, device=i.device)     # the layout gloo and RCCL share
+    dist.all_gather_into_tensor(vs, v.contiguous(), group=group)
+    dist.all_gather_into_tensor(is_, i.contiguous(), group=group)
+    return vs.view(world, B, k), is_.view(world, B, k)
+
+
 class ShardedGallery:
     def __init__(self, local_rows: torch.Tensor, n_total: int, rank: int = 0, world: int = 1,
                  engine=None, group: Optional[dist.ProcessGroup] = None):
@@ -58,10 +68,7 @@ class ShardedGallery:
         if self.world == 1:
             return v, i
         B = q_all.shape[0]
-        vs = torch.empty((self.world, B, k), dtype=v.dtype, device=v.device)
-        is_ = torch.empty((self.world, B, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(vs, v.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(is_, i.contiguous(), group=self.group)
+        vs, is_ = all_gather_topk(v, i, self.world, self.group)
         return self.engine.merge(vs, is_)
 
     def search_local_queries(self, q_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
