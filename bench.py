@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--arch", default="vit_large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,10 +99,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())     # == local_rank on a real N-GPU node
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)             # RCCL over xGMI
+        else:
+            dist.init_process_group(a.backend)
 
     from vpr_amd import _lib, ops
     _lib.lib()
