@@ -122,6 +122,18 @@ int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int
 /* Device pointer + leading dimension of the score matrix inside a workspace (for tests). */
 float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k, int* ld_out);
 
+/* fp8 variant (BASELINE config 5): operands are OCP e4m3 bytes with one f32 scale per row
+ * (value = scale * fp8).  score = fp32 rounding of (sum_i q_i*g_i, exact in f64) * q_scale * g_scale
+ * evaluated in f64 in that order; same ordering contract, same workspace size.  D % 128 == 0. */
+int vpr_knn_topk_fp8(const uint8_t* q, const float* q_scale, const uint8_t* gallery,
+                     const float* gallery_scale, int B, int N, int D, int k, int index_base,
+                     float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Per-row symmetric quantisation f32 -> e4m3: scale = max|x|/448 (1 for a zero row),
+ * q = fp8_rne(x / scale).  x [rows, D] f32 (D % 4 == 0), q [rows, D] bytes, scale [rows] f32. */
+int vpr_quantize_fp8_rows(const float* x, long long rows, int D, uint8_t* q, float* scale, void* stream);
+
 /* Merge per-shard top-k lists (after an all-gather): vals/idxs [shards, B, k] -> [B, k],
  * same ordering contract.  Entries with idx < 0 are padding. */
 int vpr_topk_merge(const float* vals, const int32_t* idxs, int shards, int B, int k,

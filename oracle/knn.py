@@ -26,6 +26,36 @@ def knn_topk(q_bf16: torch.Tensor, g_bf16: torch.Tensor, k: int, index_base: int
     return vals, idx
 
 
+def quantize_fp8_rows(x: torch.Tensor):
+    """Per-row symmetric e4m3 quantisation, as vpr_quantize_fp8_rows: scale = max|x|/448 (1 if the
+    row is zero), q = fp8_rne(x / scale).  Returns (bytes uint8 [rows,D], scale f32 [rows])."""
+    x = x.to(torch.float32)
+    m = x.abs().amax(dim=1)
+    scale = torch.where(m > 0, m / 448.0, torch.ones_like(m))
+    q = (x / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def _order_topk(s32: torch.Tensor, k: int, index_base: int):
+    B, N = s32.shape
+    order = torch.sort(-s32, dim=1, stable=True).indices[:, :k]
+    vals = torch.gather(s32, 1, order)
+    idx = order.to(torch.int32) + index_base
+    if N < k:
+        vals = torch.cat([vals, torch.full((B, k - N), float("-inf"), dtype=torch.float32)], 1)
+        idx = torch.cat([idx, torch.full((B, k - N), -1, dtype=torch.int32)], 1)
+    return vals, idx
+
+
+def knn_topk_fp8(q_u8, q_scale, g_u8, g_scale, k: int, index_base: int = 0):
+    """fp8 contract: score = f32( ((sum_i q_i g_i exact in f64) * q_scale) * g_scale ), f64 products."""
+    qf = q_u8.view(torch.float8_e4m3fn).to(torch.float64)
+    gf = g_u8.view(torch.float8_e4m3fn).to(torch.float64)
+    s = (qf @ gf.T) * q_scale.to(torch.float64)[:, None]
+    s = s * g_scale.to(torch.float64)[None, :]
+    return _order_topk(s.to(torch.float32), k, index_base)
+
+
 def topk_merge(vals: torch.Tensor, idxs: torch.Tensor):
     """vals/idxs [shards,B,k] -> [B,k] by (value desc, index asc); idx < 0 entries are padding."""
     R, B, k = vals.shape

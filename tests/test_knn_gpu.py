@@ -135,3 +135,48 @@ def test_knn_full_size_planted_recall(dev):
     # top-1 value equals the exact dot product of the planted pair
     exact = (q.double() * gal[pos].double()).sum(1).float()
     assert torch.equal(v[:, 0], exact)
+
+
+# ------------------------------------------------------------------------------------------ fp8
+def _fp8_rows(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    return oknn.quantize_fp8_rows(x)
+
+
+def test_quantize_fp8_matches_torch(dev):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(30)
+    x = torch.randn(37, 8448, generator=g) * torch.logspace(-3, 2, 37)[:, None]
+    x[5] = 0
+    q_ref, s_ref = oknn.quantize_fp8_rows(x)
+    q, s = ops.quantize_fp8_rows(x.to(dev))
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+@pytest.mark.parametrize("B,N,D,k", [(64, 3000, 8448, 10), (5, 300, 128, 3), (70, 9000, 1024, 20)])
+def test_knn_fp8_matches_oracle(dev, B, N, D, k):
+    """BASELINE config 5 arithmetic (e4m3 descriptors, per-row scale) at oracle-sized N."""
+    from vpr_amd import ops
+    q, qs = _fp8_rows(B, D, 31)
+    g, gs = _fp8_rows(N, D, 32)
+    v_ref, i_ref = oknn.knn_topk_fp8(q, qs, g, gs, k, 7)
+    v, i = ops.knn_topk_fp8(q.to(dev), qs.to(dev), g.to(dev), gs.to(dev), k, 7)
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(v.cpu(), v_ref)
+
+
+def test_knn_fp8_agrees_with_bf16_on_planted_positives(dev):
+    """fp8 keeps the retrieval answer: planted positives are still top-1 (Recall@1 = 1)."""
+    from vpr_amd import ops
+    N, D, B = 20000, 8448, 32
+    g = torch.Generator(device=dev).manual_seed(5)
+    gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    pos = torch.randint(0, N, (B,), device=dev, generator=g)
+    qf = torch.nn.functional.normalize(gal[pos] + 0.1 * torch.randn(B, D, device=dev, generator=g), dim=1)
+    g8, gs = ops.quantize_fp8_rows(gal)
+    q8, qs = ops.quantize_fp8_rows(qf)
+    _, i8 = ops.knn_topk_fp8(q8, qs, g8, gs, 5)
+    _, i16 = ops.knn_topk(qf.to(torch.bfloat16), gal.to(torch.bfloat16), 5)
+    assert torch.equal(i8[:, 0].long(), pos) and torch.equal(i16[:, 0].long(), pos)

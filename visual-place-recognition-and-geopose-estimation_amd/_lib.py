@@ -40,6 +40,9 @@ PROTOTYPES = {
     "vpr_knn_workspace_bytes": (c_size_t, [c_int] * 4),
     "vpr_knn_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_topk_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vpr_quantize_fp8_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_knn_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_knn_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),

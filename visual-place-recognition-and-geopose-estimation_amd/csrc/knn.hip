@@ -36,20 +36,28 @@ __host__ __device__ inline int knn_kp(int k) {
 // 1. score kernel.  Workgroup w owns gallery rows [N*w/nwg, N*(w+1)/nwg) — a balanced static
 // partition over a grid that is fully resident (nwg <= CUs * KNN_WG_PER_CU), so every workgroup
 // streams the same number of HBM bytes and they finish together; its rows are cut into equal
-// tiles of <= KNN_TR rows.  Per tile and K-step (64 of D): the gallery tile [th x 64] (HBM) and
-// the query tile [64 x 64] (L2) land in LDS by LDS-DMA, 2-deep ring, one barrier per K-step.
-// Wave w multiplies queries 16w..16w+15 (MFMA A operand) with every 16-row gallery block
-// (B operand): C[q][n], lane = gallery row n -> coalesced 64-B score stores.
+// tiles of <= KNN_TR rows.  Per tile and K-step (128 B of every row = 64 bf16 or 128 fp8): the
+// gallery tile [th x 128 B] (HBM) and the query tile [64 x 128 B] (L2) land in LDS by LDS-DMA,
+// 2-deep ring, one barrier per K-step.  Wave w multiplies queries 16w..16w+15 (MFMA A operand)
+// with every 16-row gallery block (B operand): C[q][n], lane = gallery row n -> coalesced 64-B
+// score stores.
+// FP8 (OCP e4m3, per-row f32 scale): same LDS image and the same 16-B fragment reads; each 16-B
+// chunk now holds 16 elements and feeds two v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes) —
+// A and B use the same (permuted) k order, so the permutation cancels in the dot product — and
+// the epilogue multiplies by the two row scales.
 // ---------------------------------------------------------------------------------------------
+template <bool FP8>
 __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
-    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G, float* __restrict__ S,
-    int B, int N, int D, int ldS) {
+    const void* __restrict__ Qv, const void* __restrict__ Gv, const float* __restrict__ q_scale,
+    const float* __restrict__ g_scale, float* __restrict__ S, int B, int N, int row_bytes, int ldS) {
   constexpr int NB = KNN_TR / 16;
   constexpr int GG = KNN_TR / 8;            // gallery staging groups (8 rows each)
   constexpr int NGRP = GG + KNN_QT / 8;     // + query staging groups
   constexpr int GPW = (NGRP + 3) / 4;       // groups per wave (upper bound)
   constexpr int STAGE_BYTES = (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const char* Q = static_cast<const char*>(Qv);
+  const char* G = static_cast<const char*>(Gv);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,25 +69,26 @@ __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
   if (len <= 0) return;
   const int ntile = (len + KNN_TR - 1) / KNN_TR;
   const int th_nom = (len + ntile - 1) / ntile;
-  const int nk = D >> 6;
+  const int nk = row_bytes >> 7;
 
   for (int t = 0; t < ntile; ++t) {
     const int row0 = (int)r_begin + t * th_nom;
-    const int th = min(th_nom, (int)r_end - row0);   // valid rows of this tile (>= 1)
+    const int th = min(th_nom, (int)r_end - row0);   // valid rows of this tile
+    if (th <= 0) break;                              // uniform; only for absurdly long row ranges
 
-    // Source row pointers of the staging groups this wave owns.
-    const uint16_t* src[GPW];
+    // Source row pointers (bytes) of the staging groups this wave owns.
+    const char* src[GPW];
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
       const int g = wave + 4 * i;
       const int tr = (g < GG ? g : g - GG) * 8 + (lane >> 3);   // row inside its tile
-      const int sw = ((lane & 7) ^ ((tr >> 1) & 7)) << 3;
+      const int sw = ((lane & 7) ^ ((tr >> 1) & 7)) << 4;
       if (g < GG) {
         const int r = row0 + min(tr, th - 1);
-        src[i] = G + (long long)r * D + sw;
+        src[i] = G + (long long)r * row_bytes + sw;
       } else {
         const int r = min(qb * KNN_QT + tr, B - 1);
-        src[i] = Q + (long long)r * D + sw;
+        src[i] = Q + (long long)r * row_bytes + sw;
       }
     }
     const int gvalid = (th + 7) >> 3;   // gallery groups that hold at least one valid row
@@ -90,9 +99,9 @@ __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
       for (int i = 0; i < GPW; ++i) {
         const int g = wave + 4 * i;
         if (g < GG) {
-          if (g < gvalid) glds16(src[i] + ks * 64, base + g * 8 * TILE_ROW_BYTES);
+          if (g < gvalid) glds16(src[i] + ks * 128, base + g * 8 * TILE_ROW_BYTES);
         } else if (g < NGRP) {
-          glds16(src[i] + ks * 64, base + KNN_TR * TILE_ROW_BYTES + (g - GG) * 8 * TILE_ROW_BYTES);
+          glds16(src[i] + ks * 128, base + KNN_TR * TILE_ROW_BYTES + (g - GG) * 8 * TILE_ROW_BYTES);
         }
       }
     };
@@ -116,21 +125,38 @@ __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
         if (nb * 16 < th) {
           const bf16x8 b0 = lds_frag(tg, 16 * nb + (lane & 15), (lane >> 4));
           const bf16x8 b1 = lds_frag(tg, 16 * nb + (lane & 15), 4 + (lane >> 4));
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nb], 0, 0, 0);
+          if constexpr (FP8) {
+            typedef __attribute__((ext_vector_type(2))) long l64x2;
+            const l64x2 A0 = __builtin_bit_cast(l64x2, a0), A1 = __builtin_bit_cast(l64x2, a1);
+            const l64x2 B0 = __builtin_bit_cast(l64x2, b0), B1 = __builtin_bit_cast(l64x2, b1);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A0[0], B0[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A0[1], B0[1], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A1[0], B1[0], acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A1[1], B1[1], acc[nb], 0, 0, 0);
+          } else {
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nb], 0, 0, 0);
+          }
         }
       }
     }
 
     // C/D map of 16x16: col (gallery row) = lane&15, row (query) = 4*(lane>>4) + e.
+    float qs[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (FP8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qs[e] = q_scale[min(qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e, B - 1)];
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int n = 16 * nb + (lane & 15);
       if (n < th) {
+        float gs = 1.f;
+        if constexpr (FP8) gs = g_scale[row0 + n];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e;
-          if (q < B) S[(long long)q * ldS + row0 + n] = acc[nb][e];
+          if (q < B) S[(long long)q * ldS + row0 + n] = FP8 ? acc[nb][e] * qs[e] * gs : acc[nb][e];
         }
       }
     }
@@ -365,10 +391,31 @@ __global__ __launch_bounds__(256) void knn_select_stream_kernel(
 // in f64 (each product is exact), in a fixed order (thread-strided 16-B chunks in sequence, wave
 // butterfly, then the 4 wave sums) -> independent of how the candidate was found.  All of a
 // thread's loads are issued before the first FMA: one trip to HBM per row.
-constexpr int RS_U = 6;   // 16-B chunks per thread per trip (256 threads x 6 x 8 = 12288 elements)
+constexpr int RS_U = 6;   // 16-B chunks per thread per trip
+__device__ __forceinline__ double dot16_bf16(const s16x8& qa, const s16x8& ga, double acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    acc = fma((double)bf16_bits_to_f32((uint16_t)qa[j]), (double)bf16_bits_to_f32((uint16_t)ga[j]), acc);
+  return acc;
+}
+__device__ __forceinline__ double dot16_fp8(const s16x8& qa, const s16x8& ga, double acc) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const i32x4 qi = __builtin_bit_cast(i32x4, qa), gi = __builtin_bit_cast(i32x4, ga);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    acc = fma((double)__builtin_amdgcn_cvt_f32_fp8(qi[w], 0), (double)__builtin_amdgcn_cvt_f32_fp8(gi[w], 0), acc);
+    acc = fma((double)__builtin_amdgcn_cvt_f32_fp8(qi[w], 1), (double)__builtin_amdgcn_cvt_f32_fp8(gi[w], 1), acc);
+    acc = fma((double)__builtin_amdgcn_cvt_f32_fp8(qi[w], 2), (double)__builtin_amdgcn_cvt_f32_fp8(gi[w], 2), acc);
+    acc = fma((double)__builtin_amdgcn_cvt_f32_fp8(qi[w], 3), (double)__builtin_amdgcn_cvt_f32_fp8(gi[w], 3), acc);
+  }
+  return acc;
+}
+
+template <bool FP8>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(
-    const int32_t* __restrict__ cand_idx, const uint16_t* __restrict__ Q, const uint16_t* __restrict__ G,
-    int D, int kp, float* __restrict__ exact) {
+    const int32_t* __restrict__ cand_idx, const void* __restrict__ Qv, const void* __restrict__ Gv,
+    const float* __restrict__ q_scale, const float* __restrict__ g_scale,
+    int row_bytes, int kp, float* __restrict__ exact) {
   __shared__ double red[4];
   const int c = blockIdx.x, b = blockIdx.y;
   const int id = cand_idx[(long long)b * kp + c];
@@ -376,9 +423,9 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(
     if (threadIdx.x == 0) exact[(long long)b * kp + c] = -INFINITY;
     return;
   }
-  const uint16_t* qrow = Q + (long long)b * D;
-  const uint16_t* grow = G + (long long)id * D;
-  const int nchunks = D >> 3;
+  const char* qrow = static_cast<const char*>(Qv) + (long long)b * row_bytes;
+  const char* grow = static_cast<const char*>(Gv) + (long long)id * row_bytes;
+  const int nchunks = row_bytes >> 4;
   double acc = 0.0;
   for (int ch0 = threadIdx.x; ch0 < nchunks; ch0 += 256 * RS_U) {
     s16x8 qa[RS_U], ga[RS_U];
@@ -386,22 +433,22 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(
     for (int u = 0; u < RS_U; ++u) {
       const int ch = ch0 + 256 * u;
       const int chc = ch < nchunks ? ch : ch0;          // clamp: always a valid address
-      qa[u] = *reinterpret_cast<const s16x8*>(qrow + chc * 8);
-      ga[u] = *reinterpret_cast<const s16x8*>(grow + chc * 8);
+      qa[u] = *reinterpret_cast<const s16x8*>(qrow + chc * 16);
+      ga[u] = *reinterpret_cast<const s16x8*>(grow + chc * 16);
     }
 #pragma unroll
     for (int u = 0; u < RS_U; ++u) {
-      if (ch0 + 256 * u < nchunks) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          acc = fma((double)bf16_bits_to_f32((uint16_t)qa[u][j]), (double)bf16_bits_to_f32((uint16_t)ga[u][j]), acc);
-      }
+      if (ch0 + 256 * u < nchunks) acc = FP8 ? dot16_fp8(qa[u], ga[u], acc) : dot16_bf16(qa[u], ga[u], acc);
     }
   }
   acc = wave_sum_f64(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) exact[(long long)b * kp + c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) {
+    double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    if (FP8) tot = (tot * (double)q_scale[b]) * (double)g_scale[id];   // same order as oracle/knn.py
+    exact[(long long)b * kp + c] = (float)tot;
+  }
 }
 
 // 3b. final order: grid (B), 128 threads.  Rank the kp rescored candidates by
@@ -513,13 +560,26 @@ static int num_cus() {
   return g_num_cu;
 }
 
-int knn_scores(const uint16_t* q, const uint16_t* g, int B, int N, int D, void* ws, size_t ws_bytes,
-               int k_for_plan, hipStream_t stream) {
+struct KnnOperands {          // bf16: scales are null; fp8: per-row f32 scales
+  const void* q; const void* g; const float* q_scale; const float* g_scale; bool fp8;
+};
+
+static int knn_check(const KnnOperands& o, int D) {
+  if (!o.q || !o.g) return VPR_ERR_INVALID_ARG;
+  if (o.fp8 && (!o.q_scale || !o.g_scale)) return VPR_ERR_INVALID_ARG;
+  if (o.fp8 && (D % 128) != 0) return VPR_ERR_UNSUPPORTED;           // 128-B K-steps
+  if ((reinterpret_cast<uintptr_t>(o.q) | reinterpret_cast<uintptr_t>(o.g)) & 15) return VPR_ERR_UNSUPPORTED;
+  return VPR_OK;
+}
+
+int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_bytes, int k_for_plan,
+               hipStream_t stream) {
   KnnPlan p;
-  if (!q || !g || !ws) return VPR_ERR_INVALID_ARG;
+  if (!ws) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k_for_plan, &p)) return VPR_ERR_UNSUPPORTED;
+  const int st = knn_check(o, D);
+  if (st != VPR_OK) return st;
   if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
-  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(g)) & 15) return VPR_ERR_UNSUPPORTED;
   float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + p.off_S);
   const int slots = num_cus() * KNN_WG_PER_CU;
   // Fully resident, balanced grid; never more workgroups than 16-row blocks of gallery.
@@ -527,16 +587,23 @@ int knn_scores(const uint16_t* q, const uint16_t* g, int B, int N, int D, void* 
   const int max_useful = (N + 15) / 16;
   if (nwg > max_useful) nwg = max_useful;
   constexpr size_t lds = 2 * (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
-  VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel, dim3(nwg, p.Bpad / KNN_QT), dim3(256), lds, stream,
-                     q, g, S, B, N, D, p.ldS));
+  const dim3 grid(nwg, p.Bpad / KNN_QT);
+  if (o.fp8)
+    VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<true>, grid, dim3(256), lds, stream, o.q, o.g, o.q_scale,
+                                 o.g_scale, S, B, N, D, p.ldS));
+  else
+    VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<false>, grid, dim3(256), lds, stream, o.q, o.g, o.q_scale,
+                                 o.g_scale, S, B, N, D * 2, p.ldS));
   return VPR_OK;
 }
 
-int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k, int index_base,
-               float* out_val, int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream) {
+int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
+               int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream) {
   KnnPlan p;
-  if (!q || !g || !ws || !out_val || !out_idx) return VPR_ERR_INVALID_ARG;
+  if (!ws || !out_val || !out_idx) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
+  const int st = knn_check(o, D);
+  if (st != VPR_OK) return st;
   if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
   char* w = static_cast<char*>(ws);
   const float* cur_v = reinterpret_cast<float*>(w + p.off_S);
@@ -558,10 +625,41 @@ int knn_select(const uint16_t* q, const uint16_t* g, int B, int N, int D, int k,
   }
   // exact scores go into the (now free) other candidate-value buffer
   float* exact = reinterpret_cast<float*>(w + p.off_cv[p.nlevel & 1]);
-  VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel, dim3(p.kp, B), dim3(256), 0, stream, cur_i, q, g, D, p.kp, exact));
+  if (o.fp8)
+    VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel<true>, dim3(p.kp, B), dim3(256), 0, stream, cur_i, o.q, o.g,
+                                 o.q_scale, o.g_scale, D, p.kp, exact));
+  else
+    VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel<false>, dim3(p.kp, B), dim3(256), 0, stream, cur_i, o.q, o.g,
+                                 o.q_scale, o.g_scale, D * 2, p.kp, exact));
   VPR_TRY_LAUNCH(launch_kernel(knn_order_kernel, dim3(B), dim3(128), 0, stream, cur_i, exact, k, p.kp,
                                index_base, out_val, out_idx));
   return VPR_OK;
+}
+
+// Per-row symmetric quantisation to OCP e4m3: scale = max|x| / 448 (1 for an all-zero row),
+// q = fp8_rne(x / scale).  One workgroup per row; v_cvt_pk_fp8_f32 does the rounding.
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __restrict__ x, int D,
+                                                                uint8_t* __restrict__ q, float* __restrict__ scale) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const float* xr = x + row * D;
+  float m = 0.f;
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + d);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = m > 0.f ? m / 448.0f : 1.0f;
+  if (threadIdx.x == 0) scale[row] = sc;
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + d);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.x / sc, v.y / sc, 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.z / sc, v.w / sc, pk, true);
+    *reinterpret_cast<int*>(q + row * D + d) = pk;
+  }
 }
 
 }  // namespace vpr
@@ -583,26 +681,53 @@ extern "C" float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k
 extern "C" int vpr_knn_scores(const uint16_t* q, const uint16_t* gallery, int B, int N, int D,
                               void* workspace, size_t workspace_bytes, void* stream) {
   // The plan's score-matrix offset does not depend on k; size checks use the caller's bytes.
-  return knn_scores(q, gallery, B, N, D, workspace, workspace_bytes, 1, static_cast<hipStream_t>(stream));
+  const KnnOperands o{q, gallery, nullptr, nullptr, false};
+  return knn_scores(o, B, N, D, workspace, workspace_bytes, 1, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
                               int index_base, float* out_val, int32_t* out_idx, void* workspace,
                               size_t workspace_bytes, void* stream) {
-  return knn_select(q, gallery, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+  const KnnOperands o{q, gallery, nullptr, nullptr, false};
+  return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream));
+}
+
+static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
+                        int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+  KnnPlan p;
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
+  if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
+  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
+  const int st = knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream));
+  if (st != VPR_OK) return st;
+  return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream));
 }
 
 extern "C" int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
                             int index_base, float* out_val, int32_t* out_idx, void* workspace,
                             size_t workspace_bytes, void* stream) {
-  KnnPlan p;
-  if (!knn_plan(B, N, D, k, &p)) return (B <= 0 || N <= 0 || D <= 0 || k <= 0) ? VPR_ERR_INVALID_ARG : VPR_ERR_UNSUPPORTED;
-  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
-  int st = knn_scores(q, gallery, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream));
-  if (st != VPR_OK) return st;
-  return knn_select(q, gallery, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
-                    static_cast<hipStream_t>(stream));
+  const KnnOperands o{q, gallery, nullptr, nullptr, false};
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vpr_knn_topk_fp8(const uint8_t* q, const float* q_scale, const uint8_t* gallery,
+                                const float* gallery_scale, int B, int N, int D, int k, int index_base,
+                                float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  const KnnOperands o{q, gallery, q_scale, gallery_scale, true};
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vpr_quantize_fp8_rows(const float* x, long long rows, int D, uint8_t* q, float* scale, void* stream) {
+  if (!x || !q || !scale || rows < 0 || D <= 0) return VPR_ERR_INVALID_ARG;
+  if ((D % 4) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(q) & 3)) return VPR_ERR_UNSUPPORTED;
+  if (rows == 0) return VPR_OK;
+  if (rows > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
+  VPR_TRY_LAUNCH(launch_kernel(quantize_fp8_rows_kernel, dim3((unsigned)rows), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), x, D, q, scale));
+  return VPR_OK;
 }
 
 extern "C" int vpr_topk_merge(const float* vals, const int32_t* idxs, int shards, int B, int k,

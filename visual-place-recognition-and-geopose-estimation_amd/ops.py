@@ -173,6 +173,38 @@ def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0
     return vals, idx
 
 
+def quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [rows, D] f32 -> (e4m3 bytes [rows, D] uint8, per-row scale [rows] f32); value = scale * fp8."""
+    _need(x, torch.float32, "x", 2)
+    rows, D = x.shape
+    q = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    st = _lib.lib().vpr_quantize_fp8_rows(_ptr(x), rows, D, _ptr(q), _ptr(scale), _stream())
+    _lib.check(st, "vpr_quantize_fp8_rows")
+    return q, scale
+
+
+def knn_topk_fp8(q: torch.Tensor, q_scale: torch.Tensor, gallery: torch.Tensor, gallery_scale: torch.Tensor,
+                 k: int, index_base: int = 0, ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp8 (e4m3 bytes + per-row f32 scale) variant of knn_topk; D % 128 == 0."""
+    _need(q, torch.uint8, "q", 2)
+    _need(gallery, torch.uint8, "gallery", 2)
+    _need(q_scale, torch.float32, "q_scale", 1)
+    _need(gallery_scale, torch.float32, "gallery_scale", 1)
+    B, D = q.shape
+    N = gallery.shape[0]
+    if gallery.shape[1] != D or q_scale.numel() != B or gallery_scale.numel() != N:
+        raise RuntimeError("knn_topk_fp8: inconsistent shapes")
+    if ws is None:
+        ws = knn_workspace(B, N, D, k, q.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
+    st = _lib.lib().vpr_knn_topk_fp8(_ptr(q), _ptr(q_scale), _ptr(gallery), _ptr(gallery_scale), B, N, D, int(k),
+                                     int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_knn_topk_fp8")
+    return vals, idx
+
+
 def knn_scores(q: torch.Tensor, gallery: torch.Tensor, ws: torch.Tensor) -> None:
     """Stage 1 only (the HBM-bound score kernel); results stay in `ws`."""
     _need(q, torch.bfloat16, "q", 2)
