@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--C", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--N8", type=int, default=125000)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -52,6 +53,26 @@ def main():
         res["knn_topk_total"] = dict(ms=med * 1e3, best_ms=best * 1e3,
                                      GBps_alg=(a.N * a.D * 2 + a.B * a.D * 2 + a.B * a.k * 8) / med / 1e9)
         del gal
+
+    if want("knn8"):
+        # fp8 gallery (BASELINE config 5 arithmetic): one GPU's share of a 1M-row gallery by default
+        N8 = a.N8
+        gal8 = torch.empty((N8, a.D), dtype=torch.uint8, device=dev)
+        gs8 = torch.empty((N8,), dtype=torch.float32, device=dev)
+        for lo in range(0, N8, 25000):
+            n = min(25000, N8 - lo)
+            x = torch.nn.functional.normalize(torch.randn(n, a.D, device=dev, generator=g), dim=1)
+            gal8[lo:lo + n], gs8[lo:lo + n] = ops.quantize_fp8_rows(x)
+        q8, qs8 = ops.quantize_fp8_rows(torch.nn.functional.normalize(torch.randn(a.B, a.D, device=dev, generator=g), dim=1))
+        ws = ops.knn_workspace(a.B, N8, a.D, a.k, dev)
+        med, best = timeit(lambda: ops.knn_topk_fp8(q8, qs8, gal8, gs8, a.k, 0, ws), a.iters)
+        byt = N8 * a.D + a.B * a.D + a.B * a.k * 8 + N8 * 4
+        res["knn_topk_fp8_total"] = dict(N=N8, ms=med * 1e3, best_ms=best * 1e3, GBps_alg=byt / med / 1e9)
+        from vpr_amd.gallery import GalleryShard, GraphedLocalTopK
+        gr = GraphedLocalTopK(GalleryShard(gal8, gs8, None, N8, 0, "fp8_e4m3"), a.B, a.k)
+        med, best = timeit(lambda: gr(q8, qs8), a.iters)
+        res["knn_topk_fp8_graph_replay"] = dict(N=N8, ms=med * 1e3, best_ms=best * 1e3, GBps_alg=byt / med / 1e9)
+        del gal8
 
     if want("salad"):
         B, C = a.B, a.C

@@ -96,3 +96,52 @@ def test_pipeline_step_shapes_and_consistency(dev):
     sep = ops.pose_head(desc, pos[0].weight, pos[0].bias, pos[2].weight, pos[2].bias)
     # block-diagonal fusion adds exact zeros; only the split-K partition (summation order) differs
     assert (out.pose[:, :2] - sep).abs().max().item() < 1e-6
+
+
+def test_graph_captured_retrieval_equals_eager(dev, tmp_path):
+    """BASELINE config 5 plumbing: the local search captured into a HIP graph and replayed with new
+    queries gives exactly the eager answer (bf16 and fp8 shards), from an on-disk gallery."""
+    from vpr_amd import gallery, ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, D, B, k = 9000, 8448, 64, 10
+    gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    labels = np.zeros((N, 4))
+    gallery.save_gallery(str(tmp_path / "g16"), gal.to(torch.bfloat16), labels)
+    g8, gs = ops.quantize_fp8_rows(gal)
+    gallery.save_gallery(str(tmp_path / "g8"), g8, labels, scales=gs)
+    for name in ("g16", "g8"):
+        shard = gallery.load_gallery_shard(str(tmp_path / name), dev, rank=1, world=2)
+        graphed = gallery.GraphedLocalTopK(shard, B, k)
+        for seed in (0, 1):
+            q = torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1)
+            if shard.dtype == "bf16":
+                q16 = q.to(torch.bfloat16)
+                v, i = graphed(q16)
+                v_ref, i_ref = ops.knn_topk(q16, shard.rows, k, shard.index_base)
+            else:
+                q8, qs = ops.quantize_fp8_rows(q)
+                v, i = graphed(q8, qs)
+                v_ref, i_ref = ops.knn_topk_fp8(q8, qs, shard.rows, shard.scales, k, shard.index_base)
+            assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+            assert int(i.min()) >= shard.index_base
+
+
+def test_config3_gallery_100k_sharded_8_ways(dev):
+    """BASELINE config 3 on one GPU: the 100k gallery cut into the 8 row shards the ranks would
+    own, searched shard by shard with global indices and merged == the unsharded search."""
+    from vpr_amd import ops
+    from vpr_amd.retrieval import shard_bounds
+    N, D, B, k, R = 100_000, 8448, 64, 10, 8
+    g = torch.Generator(device=dev).manual_seed(11)
+    gal = torch.empty((N, D), dtype=torch.bfloat16, device=dev)
+    for lo in range(0, N, 20000):
+        gal[lo:lo + 20000] = torch.nn.functional.normalize(torch.randn(20000, D, device=dev, generator=g), dim=1).to(torch.bfloat16)
+    q = torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1).to(torch.bfloat16)
+    v_all, i_all = ops.knn_topk(q, gal, k)
+    vs, is_ = [], []
+    for r in range(R):
+        lo, hi = shard_bounds(N, r, R)
+        v, i = ops.knn_topk(q, gal[lo:hi], k, index_base=lo)
+        vs.append(v), is_.append(i)
+    vm, im = ops.topk_merge(torch.stack(vs), torch.stack(is_))
+    assert torch.equal(im, i_all) and torch.equal(vm, v_all)

@@ -121,3 +121,52 @@ def test_recall_at_k():
     assert postproc.recall_at_k(idx[:, :1], [3, 1, 7]) == pytest.approx(2 / 3)
     assert postproc.recall_at_k(idx, [3, 1, 7]) == 1.0
     assert postproc.recall_at_k(idx, [[5, 9], [0], [7]]) == pytest.approx(2 / 3)
+
+
+# ------------------------------------------------------------------ gallery format / label transfer
+def test_gallery_store_roundtrip_and_sharding(tmp_path):
+    from vpr_amd import gallery
+    g = torch.Generator().manual_seed(0)
+    desc = torch.nn.functional.normalize(torch.randn(37, 128, generator=g), dim=1).to(torch.bfloat16)
+    labels = np.stack([np.arange(37) * 10.0, np.arange(37) * -3.0, (np.arange(37) * 25.0) % 360, np.arange(37) % 4], 1)
+    gallery.save_gallery(str(tmp_path / "gal"), desc, labels, filenames=[f"img_{i:04d}.jpg" for i in range(37)])
+    parts = [gallery.load_gallery_shard(str(tmp_path / "gal"), torch.device("cpu"), r, 3) for r in range(3)]
+    assert [p.index_base for p in parts] == [0, 12, 24] and sum(p.rows.shape[0] for p in parts) == 37
+    assert torch.equal(torch.cat([p.rows for p in parts]), desc)
+    assert np.array_equal(parts[1].labels, labels) and parts[0].dtype == "bf16" and parts[0].scales is None
+    # fp8 form
+    from oracle import knn as oknn_
+    q8, sc = oknn_.quantize_fp8_rows(desc.float())
+    gallery.save_gallery(str(tmp_path / "gal8"), q8, labels, scales=sc)
+    p8 = gallery.load_gallery_shard(str(tmp_path / "gal8"), torch.device("cpu"), 1, 2)
+    assert p8.dtype == "fp8_e4m3" and torch.equal(p8.rows, q8[18:]) and torch.equal(p8.scales, sc[18:])
+    with pytest.raises(ValueError):
+        gallery.save_gallery(str(tmp_path / "bad"), desc.float(), labels)
+
+
+def test_labels_csv_and_positives():
+    from vpr_amd import gallery, postproc
+    here = os.path.dirname(os.path.abspath(__file__))
+    labels, names = gallery.labels_from_csv(os.path.join(here, "golden", "labels_val_head48.csv"))
+    assert labels.shape == (48, 4) and names[0].startswith("img_")
+    pos_r = gallery.positives_by_region(labels[:5, 3], labels[:, 3])
+    assert all(i in pos_r[i] for i in range(5))
+    pos_d = gallery.positives_by_distance(labels[:5, :2], labels[:, :2], tau=50.0)
+    assert all(i in pos_d[i] for i in range(5))
+    # a query whose top-1 is itself is a hit under both rules; a far row is a miss under distance
+    far = int(np.argmax(((labels[:, :2] - labels[0, :2]) ** 2).sum(1)))
+    idx = np.array([[0], [far]])
+    assert postproc.recall_at_k(idx, [pos_d[0], pos_d[0]]) == 0.5
+
+
+def test_label_transfer_modes():
+    from vpr_amd import gallery
+    labels = np.array([[100.0, 10.0, 350.0, 1], [200.0, 20.0, 10.0, 1], [900.0, 90.0, 180.0, 2]])
+    scores = torch.tensor([[0.9, 0.9, 0.1], [0.8, 0.2, -1.0]])
+    idx = torch.tensor([[0, 1, 2], [2, 0, -1]], dtype=torch.int32)
+    top1 = gallery.label_transfer(scores, idx, labels, "top1")
+    assert np.allclose(top1, [[100, 10, 350], [900, 90, 180]])
+    w = gallery.label_transfer(scores, idx, labels, "weighted", temperature=0.01)
+    assert np.allclose(w[0, :2], [150.0, 15.0], atol=1e-6)        # equal weights on rows 0,1; row 2 negligible
+    assert min(abs(w[0, 2] - 0.0), abs(w[0, 2] - 360.0)) < 1e-6   # circular mean of 350 and 10 deg
+    assert np.allclose(w[1], [900, 90, 180], atol=1e-6)           # padding (-1) ignored
