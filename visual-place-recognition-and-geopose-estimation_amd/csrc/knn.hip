@@ -16,16 +16,15 @@
 // bit-exact against oracle/knn.py as long as the true top-k lie inside the approximate top-KP
 // (MFMA f32 error ~1e-6 vs. the k-th..KP-th score gap).
 #include <math.h>
+#include <stdlib.h>
 #include "vpr_common.cuh"
 #include "vpr_internal.h"
 
 namespace vpr {
 
-constexpr int KNN_TR = 144;        // gallery rows per tile (9 MFMA column blocks of 16)
 constexpr int KNN_QT = 64;         // queries per tile (4 waves x 16)
 constexpr int KNN_CHUNK = 4096;    // candidates per workgroup of the register-held select levels
 constexpr int KNN_STREAM_CHUNK = 8192;   // scores per workgroup of the streaming level-0 select
-constexpr int KNN_WG_PER_CU = 3;
 
 __host__ __device__ inline int knn_kp(int k) {
   int kp = 2 * k > k + 8 ? 2 * k : k + 8;
@@ -34,7 +33,7 @@ __host__ __device__ inline int knn_kp(int k) {
 
 // ---------------------------------------------------------------------------------------------
 // 1. score kernel.  Workgroup w owns gallery rows [N*w/nwg, N*(w+1)/nwg) — a balanced static
-// partition over a grid that is fully resident (nwg <= CUs * KNN_WG_PER_CU), so every workgroup
+// partition over a grid that is fully resident (nwg <= CUs * WGPC), so every workgroup
 // streams the same number of HBM bytes and they finish together; its rows are cut into equal
 // tiles of <= KNN_TR rows.  Per tile and K-step (128 B of every row = 64 bf16 or 128 fp8): the
 // gallery tile [th x 128 B] (HBM) and the query tile [64 x 128 B] (L2) land in LDS by LDS-DMA,
@@ -46,8 +45,8 @@ __host__ __device__ inline int knn_kp(int k) {
 // A and B use the same (permuted) k order, so the permutation cancels in the dot product — and
 // the epilogue multiplies by the two row scales.
 // ---------------------------------------------------------------------------------------------
-template <bool FP8>
-__global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
+template <bool FP8, int KNN_TR, int WGPC, int ABL>
+__global__ __launch_bounds__(256, WGPC) void knn_scores_kernel(
     const void* __restrict__ Qv, const void* __restrict__ Gv, const float* __restrict__ q_scale,
     const float* __restrict__ g_scale, float* __restrict__ S, int B, int N, int row_bytes, int ldS) {
   constexpr int NB = KNN_TR / 16;
@@ -101,7 +100,8 @@ __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
         if (g < GG) {
           if (g < gvalid) glds16(src[i] + ks * 128, base + g * 8 * TILE_ROW_BYTES);
         } else if (g < NGRP) {
-          glds16(src[i] + ks * 128, base + KNN_TR * TILE_ROW_BYTES + (g - GG) * 8 * TILE_ROW_BYTES);
+          if (!(ABL & 2) || ks == 0)
+            glds16(src[i] + ks * 128, base + KNN_TR * TILE_ROW_BYTES + (g - GG) * 8 * TILE_ROW_BYTES);
         }
       }
     };
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, KNN_WG_PER_CU) void knn_scores_kernel(
       const bf16x8 a1 = lds_frag(tq, 16 * wave + (lane & 15), 4 + (lane >> 4));
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
+        if ((ABL & 1) && ks > 0) break;
         if (nb * 16 < th) {
           const bf16x8 b0 = lds_frag(tg, 16 * nb + (lane & 15), (lane >> 4));
           const bf16x8 b1 = lds_frag(tg, 16 * nb + (lane & 15), 4 + (lane >> 4));
@@ -308,10 +309,12 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
 
 // 2a. level-0 select straight from the score matrix: grid (chunks, B), chunk = `ch` scores
 // (multiple of 1024, <= 8192).  Two streaming passes instead of holding the chunk in registers:
-//   pass 1  every thread finds the max KEY (value, then lower index) of its strided elements;
-//   rank    the kp-th largest of the 256 thread maxes, T, bounds the kp-th largest key of the
-//           chunk from below (keys are unique, so at most (ch/256)*(kp-1)+1 <= 4096 keys are >= T
-//           whatever the data — ties, sorted input, all-equal scores);
+//   pass 1  every thread finds the max (value, then lower index) of its strided elements with
+//           plain f32 compares (its scan order is index-ascending, so strict '>' keeps ties right);
+//   rank    T = the kp-th largest of the published maxes (64 quad maxes when kp <= 32, else the
+//           256 thread maxes) bounds the kp-th largest key of the chunk from below; keys are
+//           unique, so at most (elements per group)*(kp-1)+1 <= 4096 keys are >= T whatever the
+//           data — ties, sorted input, all-equal scores;
 //   pass 2  re-read the chunk (L2-hot) and append keys >= T to an LDS list (typically ~kp);
 //   order   each listed key counts the listed keys above it = its rank; ranks < kp are written.
 __global__ __launch_bounds__(256) void knn_select_stream_kernel(
@@ -322,50 +325,72 @@ __global__ __launch_bounds__(256) void knn_select_stream_kernel(
   const float* v = S + (long long)b * ldS;
   const int base = c * ch;
   const int len = min(ch, N - base);          // >= 1
-  unsigned long long best = KEY_DEAD;
+  float bv = -INFINITY;
+  int bi = -1;
   for (int p = tid * 4; p < len; p += 1024) {
     if (p + 4 <= len) {
       const float4 q = *reinterpret_cast<const float4*>(v + base + p);
-      unsigned long long k0 = make_key(q.x, base + p), k1 = make_key(q.y, base + p + 1);
-      unsigned long long k2 = make_key(q.z, base + p + 2), k3 = make_key(q.w, base + p + 3);
-      k0 = k1 > k0 ? k1 : k0;
-      k2 = k3 > k2 ? k3 : k2;
-      k0 = k2 > k0 ? k2 : k0;
-      best = k0 > best ? k0 : best;
+      if (q.x > bv || bi < 0) { bv = q.x; bi = base + p; }
+      if (q.y > bv) { bv = q.y; bi = base + p + 1; }
+      if (q.z > bv) { bv = q.z; bi = base + p + 2; }
+      if (q.w > bv) { bv = q.w; bi = base + p + 3; }
     } else {
       for (int e = p; e < len; ++e) {
-        const unsigned long long k = make_key(v[base + e], base + e);
-        best = k > best ? k : best;
+        const float x = v[base + e];
+        if (x > bv || bi < 0) { bv = x; bi = base + e; }
       }
     }
   }
-  sm.tmax[tid] = best;
+  unsigned long long best = bi >= 0 ? make_key(bv, bi) : KEY_DEAD;
   if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
   if (tid < kp) sm.outk[tid] = KEY_DEAD;
-  __syncthreads();
-  {
+  if (kp <= 32) {
+    unsigned long long o = dpp_u64<0xB1>(best);
+    best = o > best ? o : best;
+    o = dpp_u64<0x4E>(best);
+    best = o > best ? o : best;
+    if ((tid & 3) == 0) sm.tmax[tid >> 2] = best;
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned long long mine = sm.tmax[tid];
+      int rank = 0;
+      for (int s = 0; s < 64; s += 2) {
+        const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
+        rank += (t2.x > mine ? 1 : 0) + (t2.y > mine ? 1 : 0);
+      }
+      if (rank == kp - 1 && mine != KEY_DEAD) sm.thr = mine;   // unique keys: one writer
+    }
+  } else {
+    sm.tmax[tid] = best;
+    __syncthreads();
     int rank = 0;
     for (int s = 0; s < 256; s += 2) {
       const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
       rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
     }
-    if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;   // unique keys: one writer
+    if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;
   }
   __syncthreads();
   const unsigned long long T = sm.thr;
+  // key >= T  <=>  value > Tv, or value == Tv and index <= Ti  (T == 1: no threshold, take all)
+  const bool all = T == 1ull;
+  const float Tv = all ? -INFINITY : key_val(T);
+  const int Ti = all ? 0x7fffffff : key_idx(T);
   for (int p = tid * 4; p < len; p += 1024) {
     if (p + 4 <= len) {
       const float4 q = *reinterpret_cast<const float4*>(v + base + p);
       const float qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned long long k = make_key(qq[e], base + p + e);
-        if (k >= T) sm.cand[atomicAdd(&sm.cnt, 1)] = k;
+        const float x = qq[e];
+        if (x > Tv || (x == Tv && base + p + e <= Ti) || all)
+          sm.cand[atomicAdd(&sm.cnt, 1)] = make_key(x, base + p + e);
       }
     } else {
       for (int e = p; e < len; ++e) {
-        const unsigned long long k = make_key(v[base + e], base + e);
-        if (k >= T) sm.cand[atomicAdd(&sm.cnt, 1)] = k;
+        const float x = v[base + e];
+        if (x > Tv || (x == Tv && base + e <= Ti) || all)
+          sm.cand[atomicAdd(&sm.cnt, 1)] = make_key(x, base + e);
       }
     }
   }
@@ -448,6 +473,151 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(
     double tot = (red[0] + red[1]) + (red[2] + red[3]);
     if (FP8) tot = (tot * (double)q_scale[b]) * (double)g_scale[id];   // same order as oracle/knn.py
     exact[(long long)b * kp + c] = (float)tot;
+  }
+}
+
+// 3c. fused final stage: grid (B), 1024 threads.  Takes the level-0 candidates (<= 4096 per
+// query), selects the top-kp by MFMA score, rescoring them exactly (16 waves, every load of a
+// row issued before its first FMA, the query row staged once in LDS) and writes the ordered
+// top-k — one launch instead of select + rescore + order.  Same arithmetic as the split kernels
+// (same per-lane chunk order, same butterfly), so the results are bit-identical to them.
+constexpr int FF_NT = 512;        // 8 waves
+constexpr int FF_CPW = 3;         // candidates a wave rescoring together (all their loads in flight)
+constexpr int FF_MAXCH = 9;       // 16-B chunks per lane per row in flight per trip
+struct FinalSmem {
+  unsigned long long tmax[256];
+  unsigned long long cand[SEL_CAP];
+  unsigned long long outk[128];
+  unsigned long long thr;
+  int cnt;
+  float exact[128];
+};
+
+template <bool FP8>
+__global__ __launch_bounds__(FF_NT) void knn_final_fused_kernel(
+    const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, int L,
+    const void* __restrict__ Qv, const void* __restrict__ Gv, const float* __restrict__ q_scale,
+    const float* __restrict__ g_scale, int row_bytes, int k, int kp, int index_base,
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];      // [row_bytes] query row
+  __shared__ FinalSmem sm;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // stage the query row (16-B chunks)
+  const char* qrow = static_cast<const char*>(Qv) + (long long)b * row_bytes;
+  const int nchunks = row_bytes >> 4;
+  for (int ch = tid; ch < nchunks; ch += FF_NT)
+    *reinterpret_cast<s16x8*>(dyn + ch * 16) = *reinterpret_cast<const s16x8*>(qrow + ch * 16);
+
+  // ---- top-kp of the candidates (8 keys per thread) ----
+  unsigned long long keys[8];
+  const float* v = cand_val + (long long)b * L;
+  const int32_t* ix = cand_idx + (long long)b * L;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = i * FF_NT + tid;
+    const int pc = p < L ? p : L - 1;
+    const int id = ix[pc];
+    const float val = v[pc];
+    keys[i] = (p < L && id >= 0) ? make_key(val, id) : KEY_DEAD;
+  }
+  unsigned long long best = keys[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) best = keys[i] > best ? keys[i] : best;
+  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
+  if (tid < 128) sm.outk[tid] = KEY_DEAD;
+  {  // 256 group maxes: pairs of threads (quad-perm xor 1)
+    const unsigned long long o = dpp_u64<0xB1>(best);
+    best = o > best ? o : best;
+    if ((tid & 1) == 0) sm.tmax[tid >> 1] = best;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const unsigned long long mine = sm.tmax[tid];
+    int rank = 0;
+    for (int s2 = 0; s2 < 256; s2 += 2) {
+      const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s2]);
+      rank += (t2.x > mine ? 1 : 0) + (t2.y > mine ? 1 : 0);
+    }
+    if (rank == kp - 1 && mine != KEY_DEAD) sm.thr = mine;
+  }
+  __syncthreads();
+  const unsigned long long T = sm.thr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (keys[i] >= T) sm.cand[atomicAdd(&sm.cnt, 1)] = keys[i];
+  __syncthreads();
+  const int cn = sm.cnt;
+  for (int ci = tid; ci < cn; ci += FF_NT) {
+    const unsigned long long mine = sm.cand[ci];
+    int r = 0;
+    for (int cj = 0; cj < cn; ++cj) r += sm.cand[cj] > mine ? 1 : 0;
+    if (r < kp) sm.outk[r] = mine;
+  }
+  __syncthreads();
+
+  // ---- exact rescoring: wave w takes candidates w + 8*j; FF_CPW of them per trip, with every
+  // 16-B chunk of all their rows requested before the first FMA (one HBM round trip per trip) ----
+  for (int c0 = wave; c0 < kp; c0 += 8 * FF_CPW) {
+    int id[FF_CPW];
+    const char* grow[FF_CPW];
+    double acc[FF_CPW];
+#pragma unroll
+    for (int j = 0; j < FF_CPW; ++j) {
+      const int c = c0 + 8 * j;
+      const unsigned long long key = c < kp ? sm.outk[c] : KEY_DEAD;
+      id[j] = key == KEY_DEAD ? -1 : key_idx(key);
+      grow[j] = static_cast<const char*>(Gv) + (long long)(id[j] < 0 ? 0 : id[j]) * row_bytes;
+      acc[j] = 0.0;
+    }
+    for (int base = 0; base < nchunks; base += 64 * FF_MAXCH) {   // 2 trips at D = 8448
+      s16x8 ga[FF_CPW][FF_MAXCH];
+#pragma unroll
+      for (int j = 0; j < FF_CPW; ++j)
+#pragma unroll
+        for (int u = 0; u < FF_MAXCH; ++u) {
+          const int ch = base + lane + 64 * u;
+          ga[j][u] = *reinterpret_cast<const s16x8*>(grow[j] + (ch < nchunks ? ch : lane) * 16);
+        }
+#pragma unroll
+      for (int u = 0; u < FF_MAXCH; ++u) {
+        const int ch = base + lane + 64 * u;
+        if (ch < nchunks) {
+          const s16x8 qa = *reinterpret_cast<const s16x8*>(dyn + ch * 16);
+#pragma unroll
+          for (int j = 0; j < FF_CPW; ++j)
+            acc[j] = FP8 ? dot16_fp8(qa, ga[j][u], acc[j]) : dot16_bf16(qa, ga[j][u], acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FF_CPW; ++j) {
+      const int c = c0 + 8 * j;
+      double tot = wave_sum_f64(acc[j]);
+      if (FP8 && id[j] >= 0) tot = (tot * (double)q_scale[b]) * (double)g_scale[id[j]];
+      if (lane == 0 && c < kp) sm.exact[c] = id[j] < 0 ? -INFINITY : (float)tot;
+    }
+  }
+  __syncthreads();
+
+  // ---- final order by (f32(exact) desc, index asc) ----
+  if (tid < kp) {
+    const unsigned long long ki = sm.outk[tid];
+    int rank;
+    if (ki == KEY_DEAD) {
+      rank = tid;
+    } else {
+      const unsigned long long mine = make_key(sm.exact[tid], key_idx(ki));
+      rank = 0;
+      for (int j = 0; j < kp; ++j) {
+        const unsigned long long kj = sm.outk[j];
+        rank += (kj != KEY_DEAD && make_key(sm.exact[j], key_idx(kj)) > mine) ? 1 : 0;
+      }
+    }
+    if (rank < k) {
+      out_val[(long long)b * k + rank] = ki == KEY_DEAD ? -INFINITY : sm.exact[tid];
+      out_idx[(long long)b * k + rank] = ki == KEY_DEAD ? -1 : key_idx(ki) + index_base;
+    }
   }
 }
 
@@ -581,19 +751,44 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   if (st != VPR_OK) return st;
   if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
   float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + p.off_S);
-  const int slots = num_cus() * KNN_WG_PER_CU;
+  // Tile height / residency variants (same arithmetic, same results); 0 is the default, the
+  // others exist for A/B tuning in one process (VPR_KNN_VARIANT) and for ablation timing.
+  const char* venv = getenv("VPR_KNN_VARIANT");
+  const int variant = venv ? atoi(venv) : 0;
+  int tr = 208, wgpc = 2;                         // default: 13 row blocks, 2 workgroups per CU
+  if (variant == 2) { tr = 144; wgpc = 3; }
+  const int slots = num_cus() * wgpc;
   // Fully resident, balanced grid; never more workgroups than 16-row blocks of gallery.
   int nwg = slots;
   const int max_useful = (N + 15) / 16;
   if (nwg > max_useful) nwg = max_useful;
-  constexpr size_t lds = 2 * (KNN_TR + KNN_QT) * TILE_ROW_BYTES;
+  const size_t lds = (size_t)2 * (tr + KNN_QT) * TILE_ROW_BYTES;
   const dim3 grid(nwg, p.Bpad / KNN_QT);
-  if (o.fp8)
-    VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<true>, grid, dim3(256), lds, stream, o.q, o.g, o.q_scale,
-                                 o.g_scale, S, B, N, D, p.ldS));
-  else
-    VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<false>, grid, dim3(256), lds, stream, o.q, o.g, o.q_scale,
-                                 o.g_scale, S, B, N, D * 2, p.ldS));
+  const int rb = o.fp8 ? D : D * 2;
+#define VPR_KNN_LAUNCH(F8, TR, W, A)                                                                   \
+  do {                                                                                                 \
+    static bool attr = false;                                                                          \
+    if (!attr && lds > 65536) {                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scores_kernel<F8, TR, W, A>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
+        return VPR_ERR_LAUNCH;                                                                         \
+      attr = true;                                                                                     \
+    }                                                                                                  \
+    VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<F8, TR, W, A>, grid, dim3(256), lds, stream, o.q, o.g, \
+                                 o.q_scale, o.g_scale, S, B, N, rb, p.ldS));                           \
+  } while (0)
+  if (o.fp8) {
+    if (variant == 2) VPR_KNN_LAUNCH(true, 144, 3, 0); else VPR_KNN_LAUNCH(true, 208, 2, 0);
+  } else {
+    switch (variant) {
+      case 2: VPR_KNN_LAUNCH(false, 144, 3, 0); break;    // the round-1 first cut: 9 blocks, 3 per CU
+      case 11: VPR_KNN_LAUNCH(false, 208, 2, 1); break;   // ablation: no MFMA after the first K-step
+      case 12: VPR_KNN_LAUNCH(false, 208, 2, 2); break;   // ablation: no query staging after the first K-step
+      case 13: VPR_KNN_LAUNCH(false, 208, 2, 3); break;   // ablation: both (pure gallery stream + barriers)
+      default: VPR_KNN_LAUNCH(false, 208, 2, 0); break;
+    }
+  }
+#undef VPR_KNN_LAUNCH
   return VPR_OK;
 }
 
@@ -610,7 +805,11 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
   const int32_t* cur_i = nullptr;
   long long ld = p.ldS;
   int L = N;
-  for (int lev = 0; lev < p.nlevel; ++lev) {
+  const int rb = o.fp8 ? D : D * 2;
+  int lev = 0;
+  for (; lev < p.nlevel; ++lev) {
+    // the fused final kernel takes over as soon as the candidates of a query fit one workgroup
+    if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 48 * 1024) break;
     float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
     if (lev == 0)
@@ -623,7 +822,16 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
     L = p.nchunk[lev] * p.kp;
     ld = L;
   }
-  // exact scores go into the (now free) other candidate-value buffer
+  if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 48 * 1024) {
+    if (o.fp8)
+      VPR_TRY_LAUNCH(launch_kernel(knn_final_fused_kernel<true>, dim3(B), dim3(FF_NT), (size_t)rb, stream, cur_v,
+                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx));
+    else
+      VPR_TRY_LAUNCH(launch_kernel(knn_final_fused_kernel<false>, dim3(B), dim3(FF_NT), (size_t)rb, stream, cur_v,
+                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx));
+    return VPR_OK;
+  }
+  // general path: the last select level left the [B][kp] list; rescore and order it
   float* exact = reinterpret_cast<float*>(w + p.off_cv[p.nlevel & 1]);
   if (o.fp8)
     VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel<true>, dim3(p.kp, B), dim3(256), 0, stream, cur_i, o.q, o.g,
