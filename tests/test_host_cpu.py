@@ -170,3 +170,35 @@ def test_label_transfer_modes():
     assert np.allclose(w[0, :2], [150.0, 15.0], atol=1e-6)        # equal weights on rows 0,1; row 2 negligible
     assert min(abs(w[0, 2] - 0.0), abs(w[0, 2] - 360.0)) < 1e-6   # circular mean of 350 and 10 deg
     assert np.allclose(w[1], [900, 90, 180], atol=1e-6)           # padding (-1) ignored
+
+
+# ------------------------------------------------------------------ CSV writers
+def test_csv_writers_reproduce_reference_files(tmp_path):
+    """Round-trip the first rows of the reference's committed CSVs through our writers: the text
+    must come back byte for byte (column order, sort order, float formatting)."""
+    import pandas as pd
+    from vpr_amd import reports
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    # validation_predictions.csv (val_and_test_swin_2.py:280-293)
+    ref = open(os.path.join(here, "ref_validation_predictions_head.csv")).read()
+    df = pd.read_csv(os.path.join(here, "ref_validation_predictions_head.csv"))
+    out = tmp_path / "val.csv"
+    reports.write_validation_csv(str(out), df["filename"], df[["true_latitude", "true_longitude"]].values,
+                                 df[["predicted_latitude", "predicted_longitude"]].values)
+    assert out.read_text() == ref
+    # test_predictions_sorted.csv (:326-342) — feed shuffled rows, expect filename order back
+    ref = open(os.path.join(here, "ref_test_predictions_sorted_head.csv")).read()
+    df = pd.read_csv(os.path.join(here, "ref_test_predictions_sorted_head.csv")).sample(frac=1.0, random_state=0)
+    out = tmp_path / "test.csv"
+    reports.write_test_csv(str(out), df["filename"], df[["predicted_latitude", "predicted_longitude"]].values)
+    assert out.read_text() == ref
+    # preds.csv (swin_validation.py:121-134) — IDs from filenames, sorted by ID
+    ref = open(os.path.join(here, "ref_preds_head.csv")).read()
+    df = pd.read_csv(os.path.join(here, "ref_preds_head.csv")).sample(frac=1.0, random_state=1)
+    names = [f"img_{i:04d}.jpg" for i in df["ID"]]
+    out = tmp_path / "preds.csv"
+    reports.write_id_sorted_preds(str(out), names, df[["latitude", "longitude"]].values)
+    assert out.read_text() == ref
+    assert reports.extract_id("images_val/img_0042.jpg") == 42
+    txt = reports.format_metrics(np.array([[1.0, 2.0], [3.0, 5.0]]), np.array([[1.5, 2.0], [2.0, 3.0]]))
+    assert "MAE Latitude: 0.750000" in txt and "MAE Longitude: 1.000000" in txt
