@@ -177,6 +177,24 @@ int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, int H,
                          const float* Wh, const float* bh, int n_out, int sincos_offset,
                          float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image preprocessing on the GPU: PIL-exact antialiased resize + ToTensor + Normalize.
+ * Replaces the per-item host transforms: Resize((224,224)) -> ToTensor -> Normalize
+ *   dinov2salad/dinov2salad_validation.py:18-22, dinov2salad_finetuning.py:45-50, and the HF
+ *   image processor at swin_transformer/swin_validation.py:30.
+ * in [B,H,W,3] u8 (RGB, HWC).  kx [OW,ksize_x] / ky [OH,ksize_y] are Pillow's 22-bit fixed-point
+ * coefficients, xbounds/ybounds [out,2] = (first input index, tap count) — all device int32,
+ * produced on the host by vpr_amd.preprocess.  mean3/std3 are HOST float[3].
+ * out [B,3,OH,OW] f32 or bf16; out_u8 (optional) [B,OH,OW,3] receives the resized bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t vpr_preprocess_workspace_bytes(int B, int H, int OW);
+int vpr_preprocess_resize_normalize(const uint8_t* in, int B, int H, int W, int OH, int OW,
+                                    const int32_t* kx, const int32_t* xbounds, int ksize_x,
+                                    const int32_t* ky, const int32_t* ybounds, int ksize_y,
+                                    const float* mean3, const float* std3,
+                                    void* out, int out_is_bf16, uint8_t* out_u8,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
 int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);
 

@@ -88,3 +88,22 @@ def test_knn_merge_equals_unsharded_and_pads():
     v, i = oknn.knn_topk(q, gal[:3], 5)
     assert (i[:, 3:] == -1).all() and torch.isinf(v[:, 3:]).all()
     assert oknn.recall_at_1(i_all[:, 0], i_all[:, 0]) == 1.0
+
+
+def test_resize_tables_and_oracle_match_pil():
+    """The preprocessing restatement is pinned by PIL itself (the resizer the reference's
+    torchvision / HF transforms end in): identical bytes for both filters, down- and up-scaling."""
+    import numpy as np
+    from PIL import Image
+    from oracle import preprocess as opre
+    from vpr_amd.preprocess import resample_coeffs
+    rng = np.random.default_rng(0)
+    for (H, W) in [(480, 640), (224, 224), (200, 300), (777, 1033)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        for filt, pf in (("bilinear", Image.BILINEAR), ("bicubic", Image.BICUBIC)):
+            kx, xb, _ = resample_coeffs(W, 224, filt)
+            ky, yb, _ = resample_coeffs(H, 224, filt)
+            ref = np.asarray(Image.fromarray(img).resize((224, 224), pf))
+            assert np.array_equal(opre.resize_u8(img, 224, kx, xb, ky, yb), ref), (H, W, filt)
+    t = opre.to_tensor_normalize(np.array([[[0, 128, 255]]], dtype=np.uint8), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    assert t.shape == (3, 1, 1) and t[0, 0, 0] == -1.0 and t[2, 0, 0] == 1.0

@@ -53,6 +53,11 @@ PROTOTYPES = {
                               c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_ln_meanpool_head": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "vpr_preprocess_workspace_bytes": (c_size_t, [c_int] * 3),
+    "vpr_preprocess_resize_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                                POINTER(c_float), POINTER(c_float),
+                                                c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
 }
 
