@@ -202,3 +202,43 @@ def test_csv_writers_reproduce_reference_files(tmp_path):
     assert reports.extract_id("images_val/img_0042.jpg") == 42
     txt = reports.format_metrics(np.array([[1.0, 2.0], [3.0, 5.0]]), np.array([[1.5, 2.0], [2.0, 3.0]]))
     assert "MAE Latitude: 0.750000" in txt and "MAE Longitude: 1.000000" in txt
+
+
+# ------------------------------------------------------------------ head-only fine-tuning (§8f-4)
+def test_finetune_head_on_cached_descriptors(tmp_path):
+    """Same optimiser / loss / batch order as a reference-style loop gives the same losses; the
+    checkpoint it writes loads back through load_reference_checkpoint; the loss goes down."""
+    from vpr_amd import finetune, modules
+    torch.manual_seed(0)
+    n = 96
+    desc = torch.nn.functional.normalize(torch.randn(n, 8448), dim=1)
+    w_true = torch.randn(8448, 2) * 3
+    labels = (desc @ w_true).numpy() * np.array([900.0, 1200.0]) + np.array([219658.0, 143506.0])
+    model = modules.DINOv2RegressionModel(nn.Identity())
+    ref_head = nn.Sequential(nn.Linear(8448, 512), nn.ReLU(), nn.Linear(512, 2))
+    ref_head.load_state_dict(model.regressor.state_dict())
+    out = finetune.finetune_head(model, desc, labels, epochs=3, batch_size=16, lr=1e-3, save_dir=str(tmp_path),
+                                 val=(desc[:8], labels[:8]), seed=5, log=lambda s: None)
+    # reference-style loop (dinov2salad_finetuning.py:95-128) on the same data and batch order
+    mean, std = labels.mean(0), labels.std(0)
+    y = torch.from_numpy(((labels - mean) / std).astype(np.float32))
+    opt = torch.optim.AdamW(ref_head.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    losses = []
+    for epoch in range(3):
+        perm = torch.randperm(n, generator=g)
+        tot = 0.0
+        for lo in range(0, n, 16):
+            idx = perm[lo:lo + 16]
+            loss = nn.functional.mse_loss(ref_head(desc[idx]), y[idx])
+            opt.zero_grad(); loss.backward(); opt.step()
+            tot += float(loss)
+        losses.append(tot / 6)
+    got = [h["train_loss"] for h in out["history"]]
+    assert np.allclose(got, losses, rtol=1e-5)
+    assert got[-1] < got[0]
+    assert np.allclose(out["scaler"].mean_, mean) and np.allclose(out["scaler"].scale_, std)
+    re = modules.load_reference_checkpoint(modules.DINOv2RegressionModel(nn.Identity()), str(tmp_path / "checkpoint_2_.pth"))
+    assert torch.equal(re.regressor[0].weight, model.regressor[0].weight)
+    ck = torch.load(tmp_path / "checkpoint_2_.pth", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
