@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--arch", default="vit_large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fold", action="store_true", help="keep LayerScale as separate multiplies (A/B)")
+    ap.add_argument("--no-tune", action="store_true", help="no hipBLASLt kernel autotune (TunableOp) in warm-up")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -121,6 +123,8 @@ def main():
             nn.init.normal_(p, std=0.02)
     ext_state = {k: v.clone() for k, v in ext32.state_dict().items()}
     ext = ext32.to(dev).to(torch.bfloat16)
+    if not a.no_fold:
+        ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))
     ang = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))
     head = FusedGeoPoseHead(pos.to(dev), ang.to(dev), normalize=True)
@@ -139,8 +143,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    from vpr_amd.backbone import gemm_autotune
+    if not a.no_tune:
+        gemm_autotune(True, tuning=True)        # picks the backbone GEMM kernels during warm-up
+    for _ in range(max(a.warmup, 1)):
         pipe.step(images)
+    if not a.no_tune:
+        torch.cuda.synchronize()
+        gemm_autotune(True, tuning=False)       # timed region: replay only
     pipe.knn_events = []
     sync()
     t0 = time.perf_counter()

@@ -14,6 +14,22 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+def gemm_autotune(enable: bool = True, tuning: bool = True, max_ms_per_gemm: int = 30) -> None:
+    """PyTorch TunableOp for the backbone's four hipBLASLt GEMM shapes: during the (untimed) warm-up
+    steps each new shape is timed against the library's candidate kernels and the fastest is kept
+    in memory (PyTorch also dumps them to a scratch file in the temp dir at exit); call
+    gemm_autotune(True, tuning=False) afterwards so the timed region only replays the choices.
+    Plumbing around the library GEMMs, not a kernel."""
+    import os
+    import tempfile
+    import torch.cuda.tunable as tun
+    tun.enable(enable)
+    tun.tuning_enable(enable and tuning)
+    if enable and tuning:
+        tun.set_max_tuning_duration(max_ms_per_gemm)
+        tun.set_filename(os.path.join(tempfile.gettempdir(), f"vpr_tunableop_{os.getpid()}.csv"))
+
+
 CONFIGS = {
     # name: (embed_dim, depth, heads)
     "vit_small": (384, 12, 6),
@@ -35,12 +51,29 @@ class Block(nn.Module):
         self.fc2 = nn.Linear(int(dim * mlp_ratio), dim)
         self.ls2 = nn.Parameter(init_values * torch.ones(dim))
 
+    folded = False      # inference-only: LayerScale folded into proj / fc2 (saves two passes per block)
+
+    @torch.no_grad()
+    def fold_layerscale(self) -> None:
+        """ls * (W a + b) == (diag(ls) W) a + ls * b: rewrite proj / fc2 once, then skip the two
+        elementwise multiplies in forward.  Changes rounding only (bf16 weights are re-rounded)."""
+        if self.folded:
+            return
+        for lin, ls in ((self.proj, self.ls1), (self.fc2, self.ls2)):
+            w = (ls.float()[:, None] * lin.weight.float()).to(lin.weight.dtype)
+            b = (ls.float() * lin.bias.float()).to(lin.bias.dtype)
+            lin.weight.copy_(w)
+            lin.bias.copy_(b)
+        self.folded = True
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, T, C = x.shape
         qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-        x = x + self.ls1 * self.proj(a.transpose(1, 2).reshape(B, T, C))
-        x = x + self.ls2 * self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        y = self.proj(a.transpose(1, 2).reshape(B, T, C))
+        x = x + (y if self.folded else self.ls1 * y)
+        y = self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        x = x + (y if self.folded else self.ls2 * y)
         return x
 
 
@@ -67,6 +100,11 @@ class DinoV2(nn.Module):
         for blk in self.blocks:
             x = blk(x)
         return self.norm(x).contiguous()
+
+    def fold_layerscale(self) -> "DinoV2":
+        for blk in self.blocks:
+            blk.fold_layerscale()
+        return self
 
     def flops_per_image(self) -> float:
         T, C, L = 1 + self.num_patches, self.embed_dim, len(self.blocks)
