@@ -195,6 +195,12 @@ int vpr_preprocess_resize_normalize(const uint8_t* in, int B, int H, int W, int 
                                     void* out, int out_is_bf16, uint8_t* out_u8,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Row LayerNorm on bf16 activations (backbone helper; PyTorch semantics, f32 statistics):
+ * y[r,:] = (x[r,:] - mean) / sqrt(var + eps) * gamma + beta.  x,y [M,C] bf16; gamma/beta [C] bf16 or f32.
+ * C % 8 == 0, C <= 2048. */
+int vpr_layernorm_bf16(const uint16_t* x, const void* gamma, const void* beta, int params_are_bf16,
+                       float eps, uint16_t* y, long long M, int C, void* stream);
+
 /* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
 int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);
 

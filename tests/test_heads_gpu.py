@@ -86,3 +86,18 @@ def test_ln_meanpool_head(dev, B, T, H, dtype):
     assert (out.cpu().double() - out_ref).abs().max().item() < TOL
     pooled_only, none = ops.ln_meanpool_head(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
     assert none is None and torch.equal(pooled_only, pooled)
+
+
+@pytest.mark.parametrize("M,C,pdtype", [(16448, 1024, torch.bfloat16), (514, 384, torch.bfloat16), (7, 768, torch.float32),
+                                        (3, 2048, torch.float32)])
+def test_layernorm_bf16_matches_torch(dev, M, C, pdtype):
+    """Backbone LayerNorm kernel vs an f64 LayerNorm of the same bf16 inputs (output within one bf16 ulp)."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(pdtype)
+    beta = (0.1 * torch.randn(C, generator=g)).to(pdtype)
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-6)
+    y = ops.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6).cpu()
+    err = (y.double() - ref).abs()
+    assert (err <= 2 ** -8 * ref.abs() + 1e-6).all()      # within one bf16 rounding of the exact value

@@ -38,6 +38,14 @@ CONFIGS = {
 }
 
 
+def _ln(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+    """LayerNorm: the hand-written HIP kernel for GPU bf16 activations, PyTorch's otherwise (CPU)."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
+        from . import ops
+        return ops.layernorm_bf16(x, norm.weight, norm.bias, norm.eps)
+    return norm(x)
+
+
 class Block(nn.Module):
     def __init__(self, dim: int, heads: int, mlp_ratio: float = 4.0, init_values: float = 1e-5):
         super().__init__()
@@ -68,11 +76,11 @@ class Block(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, T, C = x.shape
-        qkv = self.qkv(self.norm1(x)).view(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(_ln(self.norm1, x)).view(B, T, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
         y = self.proj(a.transpose(1, 2).reshape(B, T, C))
         x = x + (y if self.folded else self.ls1 * y)
-        y = self.fc2(F.gelu(self.fc1(self.norm2(x))))
+        y = self.fc2(F.gelu(self.fc1(_ln(self.norm2, x))))
         x = x + (y if self.folded else self.ls2 * y)
         return x
 
@@ -99,7 +107,7 @@ class DinoV2(nn.Module):
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
         for blk in self.blocks:
             x = blk(x)
-        return self.norm(x).contiguous()
+        return _ln(self.norm, x).contiguous()
 
     def fold_layerscale(self) -> "DinoV2":
         for blk in self.blocks:

@@ -1,0 +1,95 @@
+// layernorm.hip — row LayerNorm for bf16 activations (the DINOv2 backbone calls it 49 times per
+// forward: 2 per block + the final norm; PyTorch's kernel reaches ~2 TB/s on [16448, 1024]).
+// HBM-bound: algorithmic bytes = 2 * M * C * 2.  One wave per row, 4 rows per workgroup, every
+// lane holds its 16-B chunks in registers (chunk = lane + 64*i), two-pass statistics in f32
+// (mean, then centred sum of squares) like torch, output rounded once to bf16.
+#include "vpr_common.cuh"
+#include "vpr_internal.h"
+
+namespace vpr {
+
+template <int NCH, typename ParamT>
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(
+    const uint16_t* __restrict__ x, const ParamT* __restrict__ gamma, const ParamT* __restrict__ beta,
+    float eps, uint16_t* __restrict__ y, long long M, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nchunks = C >> 3;
+  const uint16_t* xr = x + row * C;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      const s16x8 q = *reinterpret_cast<const s16x8*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = bf16_bits_to_f32((uint16_t)q[e]); s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (lane + 64 * i < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss = fmaf(d, d, ss); }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+  uint16_t* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nchunks) {
+      s16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g, b;
+        if constexpr (sizeof(ParamT) == 2) {
+          g = bf16_bits_to_f32((uint16_t)gamma[ch * 8 + e]);
+          b = bf16_bits_to_f32((uint16_t)beta[ch * 8 + e]);
+        } else {
+          g = gamma[ch * 8 + e];
+          b = beta[ch * 8 + e];
+        }
+        o[e] = (short)f32_to_bf16_bits((v[i][e] - mean) * rstd * g + b);
+      }
+      *reinterpret_cast<s16x8*>(yr + ch * 8) = o;
+    }
+  }
+}
+
+template <typename ParamT>
+static int launch_ln(const uint16_t* x, const ParamT* g, const ParamT* b, float eps, uint16_t* y, long long M,
+                     int C, hipStream_t stream) {
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const int nch = (C / 8 + 63) / 64;
+  switch (nch) {
+    case 1: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<1, ParamT>, grid, dim3(256), 0, stream, x, g, b, eps, y, M, C)); break;
+    case 2: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<2, ParamT>, grid, dim3(256), 0, stream, x, g, b, eps, y, M, C)); break;
+    case 3: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<3, ParamT>, grid, dim3(256), 0, stream, x, g, b, eps, y, M, C)); break;
+    case 4: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<4, ParamT>, grid, dim3(256), 0, stream, x, g, b, eps, y, M, C)); break;
+    default: return VPR_ERR_UNSUPPORTED;
+  }
+  return VPR_OK;
+}
+
+}  // namespace vpr
+
+using namespace vpr;
+
+extern "C" int vpr_layernorm_bf16(const uint16_t* x, const void* gamma, const void* beta, int params_are_bf16,
+                                  float eps, uint16_t* y, long long M, int C, void* stream) {
+  if (!x || !gamma || !beta || !y || M < 0 || C <= 0) return VPR_ERR_INVALID_ARG;
+  if (M == 0) return VPR_OK;
+  if ((C % 8) || C > 2048 || M > 0x1fffffffcLL) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VPR_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (params_are_bf16)
+    return launch_ln<uint16_t>(x, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
+  return launch_ln<float>(x, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
+}

@@ -313,3 +313,20 @@ def f32_to_bf16(src: torch.Tensor) -> torch.Tensor:
     st = _lib.lib().vpr_f32_to_bf16(_ptr(src), _ptr(dst), src.numel(), _stream())
     _lib.check(st, "vpr_f32_to_bf16")
     return dst
+
+
+def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """LayerNorm over the last dim of a contiguous bf16 tensor (gamma/beta bf16 or f32) -> bf16."""
+    _need(x, torch.bfloat16, "x")
+    if gamma.dtype not in (torch.bfloat16, torch.float32) or beta.dtype != gamma.dtype:
+        raise RuntimeError("layernorm_bf16: gamma/beta must both be bf16 or both f32")
+    _need(gamma, gamma.dtype, "gamma", 1)
+    _need(beta, beta.dtype, "beta", 1)
+    C = x.shape[-1]
+    if gamma.numel() != C or beta.numel() != C:
+        raise RuntimeError("layernorm_bf16: parameter size")
+    y = torch.empty_like(x)
+    st = _lib.lib().vpr_layernorm_bf16(_ptr(x), _ptr(gamma), _ptr(beta), int(gamma.dtype == torch.bfloat16), float(eps),
+                                       _ptr(y), x.numel() // C, C, _stream())
+    _lib.check(st, "vpr_layernorm_bf16")
+    return y
