@@ -201,6 +201,12 @@ int vpr_preprocess_resize_normalize(const uint8_t* in, int B, int H, int W, int 
 int vpr_layernorm_bf16(const uint16_t* x, const void* gamma, const void* beta, int params_are_bf16,
                        float eps, uint16_t* y, long long M, int C, void* stream);
 
+/* Residual add fused with the LayerNorm that follows it: sum_out = bf16(x + res); y = LayerNorm(sum_out).
+ * Same shapes / constraints as vpr_layernorm_bf16; sum_out may alias x. */
+int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const void* gamma,
+                           const void* beta, int params_are_bf16, float eps, uint16_t* y, long long M,
+                           int C, void* stream);
+
 /* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
 int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);
 

@@ -101,3 +101,36 @@ def test_layernorm_bf16_matches_torch(dev, M, C, pdtype):
     y = ops.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6).cpu()
     err = (y.double() - ref).abs()
     assert (err <= 2 ** -8 * ref.abs() + 1e-6).all()      # within one bf16 rounding of the exact value
+
+
+def test_add_layernorm_equals_add_then_layernorm(dev):
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1000, 1024, generator=g).to(torch.bfloat16).to(dev)
+    r = (torch.randn(1000, 1024, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.1 * torch.randn(1024, generator=g)).to(torch.bfloat16).to(dev)
+    beta = (0.1 * torch.randn(1024, generator=g)).to(torch.bfloat16).to(dev)
+    s, y = ops.add_layernorm_bf16(x, r, gamma, beta, 1e-6)
+    assert torch.equal(s, x + r)                                   # bf16 add, rounded once, as torch
+    assert torch.equal(y, ops.layernorm_bf16(x + r, gamma, beta, 1e-6))
+
+
+def test_backbone_hip_path_matches_block_loop(dev):
+    """DinoV2._forward_hip (fused add+LN) gives the same tokens as the plain block loop."""
+    from vpr_amd.backbone import DinoV2
+    torch.manual_seed(0)
+    m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
+    for b in m.blocks:
+        torch.nn.init.normal_(b.ls1, std=0.3)
+        torch.nn.init.normal_(b.ls2, std=0.3)
+    m.fold_layerscale()
+    x = torch.randn(3, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        fast = m(x)
+        t = m.patch_embed(x).flatten(2).transpose(1, 2)
+        t = torch.cat([m.cls_token.expand(3, -1, -1), t], dim=1) + m.pos_embed
+        for blk in m.blocks:
+            t = blk(t)
+        slow = torch.nn.functional.layer_norm(t.float(), (384,), m.norm.weight.float(), m.norm.bias.float(), 1e-6)
+    assert fast.shape == (3, 257, 384)
+    assert (fast.float() - slow).abs().max().item() < 0.06        # bf16 activations through 12 blocks

@@ -105,9 +105,33 @@ class DinoV2(nn.Module):
         """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous."""
         x = self.patch_embed(x).flatten(2).transpose(1, 2)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        if self._hip_ok(x):
+            return self._forward_hip(x)
         for blk in self.blocks:
             x = blk(x)
         return _ln(self.norm, x).contiguous()
+
+    def _hip_ok(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
+                and all(b.folded for b in self.blocks))
+
+    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+        """Same math as the block loop with every residual add fused into the LayerNorm that
+        follows it (vpr_add_layernorm_bf16): x carries the residual stream, h the normalised copy."""
+        from . import ops
+        B, T, C = x.shape
+        x = x.contiguous()
+        blocks = self.blocks
+        h = ops.layernorm_bf16(x, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+        for i, blk in enumerate(blocks):
+            qkv = blk.qkv(h).view(B, T, 3, blk.heads, C // blk.heads).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+            y = blk.proj(a.transpose(1, 2).reshape(B, T, C))
+            x, h = ops.add_layernorm_bf16(x, y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            y = blk.fc2(F.gelu(blk.fc1(h)))
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
+            x, h = ops.add_layernorm_bf16(x, y, nxt.weight, nxt.bias, nxt.eps)
+        return h
 
     def fold_layerscale(self) -> "DinoV2":
         for blk in self.blocks:

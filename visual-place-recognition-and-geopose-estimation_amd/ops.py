@@ -330,3 +330,23 @@ def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
                                        _ptr(y), x.numel() // C, C, _stream())
     _lib.check(st, "vpr_layernorm_bf16")
     return y
+
+
+def add_layernorm_bf16(x: torch.Tensor, res: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                       eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x + res rounded to bf16, LayerNorm of that sum): the residual add fused into the next norm."""
+    _need(x, torch.bfloat16, "x")
+    _need(res, torch.bfloat16, "res")
+    if res.shape != x.shape:
+        raise RuntimeError("add_layernorm_bf16: x and res shapes differ")
+    if gamma.dtype not in (torch.bfloat16, torch.float32) or beta.dtype != gamma.dtype:
+        raise RuntimeError("add_layernorm_bf16: gamma/beta must both be bf16 or both f32")
+    C = x.shape[-1]
+    if gamma.numel() != C or beta.numel() != C:
+        raise RuntimeError("add_layernorm_bf16: parameter size")
+    s, y = torch.empty_like(x), torch.empty_like(x)
+    st = _lib.lib().vpr_add_layernorm_bf16(_ptr(x), _ptr(res), _ptr(s), _ptr(gamma), _ptr(beta),
+                                           int(gamma.dtype == torch.bfloat16), float(eps), _ptr(y),
+                                           x.numel() // C, C, _stream())
+    _lib.check(st, "vpr_add_layernorm_bf16")
+    return s, y
