@@ -207,6 +207,11 @@ int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum
                            const void* beta, int params_are_bf16, float eps, uint16_t* y, long long M,
                            int C, void* stream);
 
+/* Multi-head self-attention for short ViT sequences (backbone helper): softmax(q k^T * scale) v, non-causal.
+ * qkv [B, T, 3, H, 64] bf16 (the fused projection output), out [B, T, H*64] bf16.  T <= 288, head_dim == 64. */
+int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,
+                           float scale, void* stream);
+
 /* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
 int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);
 

@@ -134,3 +134,22 @@ def test_backbone_hip_path_matches_block_loop(dev):
         slow = torch.nn.functional.layer_norm(t.float(), (384,), m.norm.weight.float(), m.norm.bias.float(), 1e-6)
     assert fast.shape == (3, 257, 384)
     assert (fast.float() - slow).abs().max().item() < 0.06        # bf16 activations through 12 blocks
+
+
+@pytest.mark.parametrize("B,T,H", [(64, 257, 16), (2, 257, 6), (3, 100, 2), (1, 288, 1), (2, 17, 3)])
+def test_attention_matches_f64_reference(dev, B, T, H):
+    """Short-sequence attention kernel vs softmax(q k^T / 8) v in f64 on the same bf16 inputs
+    (P is rounded to bf16 before P·V, as in every flash kernel: tolerance 2e-2 of the value range)."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * 1.5).to(torch.bfloat16)
+    q, k, v = qkv.double().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v          # [B,H,T,64]
+    ref = ref.transpose(1, 2).reshape(B, T, H * 64)
+    out = ops.attention_qkv_bf16(qkv.to(dev), H).cpu().double()
+    err = (out - ref).abs().max().item()
+    print("attention max err", err)
+    assert err < 2e-2
+    sdpa = torch.nn.functional.scaled_dot_product_attention(
+        *[t.to(dev) for t in qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)]).transpose(1, 2).reshape(B, T, H * 64)
+    assert (out - sdpa.cpu().double()).abs().max().item() < 3e-2               # and close to PyTorch's kernel

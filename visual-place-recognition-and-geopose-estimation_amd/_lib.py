@@ -61,6 +61,7 @@ PROTOTYPES = {
     "vpr_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_longlong, c_int, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),
+    "vpr_attention_qkv_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "vpr_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
 }
 

@@ -123,10 +123,14 @@ class DinoV2(nn.Module):
         x = x.contiguous()
         blocks = self.blocks
         h = ops.layernorm_bf16(x, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+        hip_attn = (C // blocks[0].heads == 64) and T <= 288      # the short-sequence HIP kernel's domain
         for i, blk in enumerate(blocks):
-            qkv = blk.qkv(h).view(B, T, 3, blk.heads, C // blk.heads).permute(2, 0, 3, 1, 4)
-            a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
-            y = blk.proj(a.transpose(1, 2).reshape(B, T, C))
+            if hip_attn:
+                a = ops.attention_qkv_bf16(blk.qkv(h), blk.heads)
+            else:
+                qkv = blk.qkv(h).view(B, T, 3, blk.heads, C // blk.heads).permute(2, 0, 3, 1, 4)
+                a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, C)
+            y = blk.proj(a)
             x, h = ops.add_layernorm_bf16(x, y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             y = blk.fc2(F.gelu(blk.fc1(h)))
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm

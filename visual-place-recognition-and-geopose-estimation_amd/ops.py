@@ -350,3 +350,16 @@ def add_layernorm_bf16(x: torch.Tensor, res: torch.Tensor, gamma: torch.Tensor, 
                                            x.numel() // C, C, _stream())
     _lib.check(st, "vpr_add_layernorm_bf16")
     return s, y
+
+
+def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv [B, T, 3*H*64] bf16 (fused projection output) -> softmax(q k^T / 8) v as [B, T, H*64] bf16."""
+    _need(qkv, torch.bfloat16, "qkv", 3)
+    B, T, C3 = qkv.shape
+    C = C3 // 3
+    if C3 != 3 * C or C % heads or C // heads != 64:
+        raise RuntimeError("attention_qkv_bf16: needs head_dim 64 and a [B,T,3*H*64] input")
+    out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
+    st = _lib.lib().vpr_attention_qkv_bf16(_ptr(qkv), _ptr(out), B, T, heads, 64, 0.125, _stream())
+    _lib.check(st, "vpr_attention_qkv_bf16")
+    return out
