@@ -32,6 +32,8 @@ def _check(dev, B, N, D, k, seed=0, index_base=0):
     (64, 4097, 256, 10),       # one element into the second chunk
     (100, 5000, 512, 64),      # B not a multiple of 64, max k
     (17, 12500, 1024, 10),     # one 8-way shard of the 100k gallery (rows), reduced D
+    (300, 3000, 512, 10),      # >= 256 queries: the GEMM-shaped score path (all-gathered multi-GPU batch)
+    (512, 12500, 128, 10),     # 8 ranks x 64 queries against one shard's rows
 ])
 def test_knn_matches_oracle(dev, B, N, D, k):
     _check(dev, B, N, D, k)
