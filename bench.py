@@ -64,9 +64,10 @@ def cpu_baseline(ext_state, arch, head_mods, images_cpu, gallery_sample_cpu, n_t
     t0 = time.perf_counter()
     desc = osalad.salad_aggregate(tokens, w, float(agg.dust_bin), 3, dtype=torch.float32, quantize=False)
     t_salad = time.perf_counter() - t0
-    q = desc.to(torch.bfloat16)
+    q = desc.to(torch.bfloat16).float()
+    gal32 = gallery_sample_cpu.float()                    # a CPU deployment would hold the gallery in fp32
     t0 = time.perf_counter()
-    s = q.float() @ gallery_sample_cpu.float().T          # fp32 brute force, all cores
+    s = q @ gal32.T                                       # fp32 brute force, all threads
     torch.topk(s, k, dim=1)
     t_knn = (time.perf_counter() - t0) * (n_total / gallery_sample_cpu.shape[0])
     W1, b1, W2, b2 = head_mods
@@ -217,8 +218,8 @@ def main():
             "stages": stages,
         }
         if world == 1 and not a.no_cpu_baseline:
-            sample = shard[: min(20000, n_shard)].cpu()
-            res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images[:2].cpu(), sample, a.gallery, a.k)
+            sample = shard.cpu()                                # whole gallery: the sample is one full step
+            res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images.cpu(), sample, a.gallery, a.k)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
