@@ -152,4 +152,5 @@ def test_attention_matches_f64_reference(dev, B, T, H):
     assert err < 2e-2
     sdpa = torch.nn.functional.scaled_dot_product_attention(
         *[t.to(dev) for t in qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)]).transpose(1, 2).reshape(B, T, H * 64)
-    assert (out - sdpa.cpu().double()).abs().max().item() < 3e-2               # and close to PyTorch's kernel
+    # and within two bf16 ulps (outputs reach |x| ~ 6, ulp 0.031) of PyTorch's own kernel
+    assert (out - sdpa.cpu().double()).abs().max().item() < 7e-2

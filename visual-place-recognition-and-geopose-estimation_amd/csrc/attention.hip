@@ -18,6 +18,125 @@ namespace vpr {
 
 constexpr int AT_D = 64;          // head dim
 constexpr int AT_KP = 288;        // padded keys (18 blocks of 16 = 9 MFMA k-steps of 32)
+constexpr int AT_MAXT = 5;        // query tiles per wave: ceil(18 / 4)
+
+// V is only ever read through ds_read_b64_tr_b16; chunk c of key row r sits at c ^ (r & 7), which
+// makes every 32-lane half of those reads bank-conflict-free (the K swizzle would be 2-way).
+__device__ __forceinline__ int vtile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+struct AttnCtx {
+  const char* Ks; const char* Vs; const uint16_t* qb; long long tok_stride; int T, qcol, g, trq, trp;
+  float scale_log2e; uint16_t* out; long long out_stride;
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// Q^T fragments (B operand) of query tile qt: lane (query = lane&15, group g) holds Q[query][32s + 8g .. +7]
+__device__ __forceinline__ void attn_load_q(const AttnCtx& cx, int qt, bf16x8 (&bq)[2]) {
+  const int qrow = min(qt * 16 + cx.qcol, cx.T - 1);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    bq[s] = *reinterpret_cast<const bf16x8*>(cx.qb + qrow * cx.tok_stride + 32 * s + 8 * cx.g);
+}
+// S^T block kb = K[16kb..16kb+15] Q^T; C/D: col = query (lane&15), row = key 4g+e of the block
+__device__ __forceinline__ f32x4 attn_qk_block(const AttnCtx& cx, int kb, const bf16x8 (&bq)[2]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(cx.Ks, 16 * kb + cx.qcol, cx.g + 4 * s), bq[s], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void attn_qk_all(const AttnCtx& cx, const bf16x8 (&bq)[2], f32x4 (&sc)[AT_KP / 16]) {
+#pragma unroll
+  for (int kb = 0; kb < AT_KP / 16; ++kb) {
+    sc[kb] = attn_qk_block(cx, kb, bq);
+    if ((kb % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// Row max over keys.  No masking: padded K rows are zero, so padded keys score exactly 0; they may
+// only raise the stabiliser (still an upper bound of the row), their V rows are zero, and their
+// exp2 terms are subtracted from the row sum in phase 2 (AT_KP - T of them per row).
+__device__ __forceinline__ float attn_rowmax(const f32x4 (&sc)[AT_KP / 16]) {
+  float mx = sc[0][0];
+#pragma unroll
+  for (int kb = 0; kb < AT_KP / 16; ++kb) {     // two v_max3_f32 per block
+    mx = fmaxf(fmaxf(mx, sc[kb][0]), sc[kb][1]);
+    mx = fmaxf(fmaxf(mx, sc[kb][2]), sc[kb][3]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  return fmaxf(mx, __shfl_xor(mx, 32, 64));
+}
+// phase 1: p = exp2(fma(s, c, -max*c)) of the current tile -> bf16 B operands pb (k-step t packs key
+// blocks 2t (j<4) and 2t+1 (j>=4)); meanwhile the QK^T blocks 2t, 2t+1 of the next tile,
+// written IN PLACE over the score registers just consumed (one score buffer, 72 VGPRs).
+__device__ __forceinline__ float attn_phase1(const AttnCtx& cx, f32x4 (&sc)[AT_KP / 16], float mx,
+                                             bf16x8 (&pb)[AT_KP / 32], bool has_next, const bf16x8 (&bq)[2]) {
+  const float nm = -mx * cx.scale_log2e;
+#pragma unroll
+  for (int t = 0; t < AT_KP / 32; ++t) {
+    float p[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[e] = __builtin_amdgcn_exp2f(fmaf(sc[2 * t][e], cx.scale_log2e, nm));
+      p[4 + e] = __builtin_amdgcn_exp2f(fmaf(sc[2 * t + 1][e], cx.scale_log2e, nm));
+    }
+    if (has_next) {   // wave-uniform; the score registers of blocks 2t, 2t+1 are free again: the
+      sc[2 * t] = attn_qk_block(cx, 2 * t, bq);           // next tile's S^T lands in place
+      sc[2 * t + 1] = attn_qk_block(cx, 2 * t + 1, bq);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pb[t][j] = (__bf16)p[j];
+  }
+  // what one padded key contributes to the row sum (bf16-rounded like every p): removed in phase 2
+  return (float)(__bf16)__builtin_amdgcn_exp2f(nm);
+}
+// phase 2: O^T = V^T P^T of the current tile (4 blocks of 16 dims; A = V^T by ds_read_b64_tr_b16:
+// lane 4q+p of a 16-lane group supplies the address of key row k0+q, dims 4p..4p+3 and receives
+// dim `lane&15` of those 4 keys: j=0..3 from block 2t (k0 = 32t+4g), j=4..7 from block 2t+1),
+// normalise, store; meanwhile the row max of the next tile.
+__device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&pb)[AT_KP / 32], float ppad,
+                                             int qt, bool has_next, const f32x4 (&sn)[AT_KP / 16]) {
+  // The row sum rides on the matrix pipe: a fifth "dim block" whose A operand is all ones gives
+  // sum_k P^T[k][query] in every row of its accumulator — 9 MFMAs instead of 72 VALU adds and two
+  // cross-lane steps, and it sums exactly the bf16 p values the numerator uses.
+  const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+  f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < AT_KP / 32; ++t) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[t], sacc, 0, 0, 0);
+  f32x4 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < AT_KP / 32; ++t) {
+      const int r0 = 32 * t + 4 * cx.g + cx.trq;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(cx.Vs + vtile_off(r0, 2 * db + (cx.trp >> 1)) + 8 * (cx.trp & 1)));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(cx.Vs + vtile_off(r0 + 16, 2 * db + (cx.trp >> 1)) + 8 * (cx.trp & 1)));
+      const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pb[t], oacc[db], 0, 0, 0);
+      if ((t % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const float inv = 1.0f / (sacc[0] - (float)(AT_KP - cx.T) * ppad);   // minus the AT_KP - T padded keys
+  float mxn = 0.f;
+  if (has_next) mxn = attn_rowmax(sn);
+  // C/D: col = query (lane&15), row = dim 16db + 4g + e  -> 8-byte stores of 4 consecutive dims
+  const int q = qt * 16 + cx.qcol;
+  if (q < cx.T) {
+    uint16_t* orow = cx.out + q * cx.out_stride;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      ushort4 o;
+      o.x = f32_to_bf16_bits(oacc[db][0] * inv);
+      o.y = f32_to_bf16_bits(oacc[db][1] * inv);
+      o.z = f32_to_bf16_bits(oacc[db][2] * inv);
+      o.w = f32_to_bf16_bits(oacc[db][3] * inv);
+      *reinterpret_cast<ushort4*>(orow + 16 * db + 4 * cx.g) = o;
+    }
+  }
+  return mxn;
+}
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int H, float scale_log2e) {
@@ -31,6 +150,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   const uint16_t* kb_ = qb + (long long)H * AT_D;
   const uint16_t* vb = qb + 2LL * H * AT_D;
 
+  // Q fragments of all of this wave's query tiles (qt = wave + 4j) are requested first, so their
+  // latency hides under the K/V staging instead of stalling every tile.
+  bf16x8 qf[AT_MAXT][2];
+  {
+    AttnCtx c0;
+    c0.qb = qb; c0.tok_stride = tok_stride; c0.T = T; c0.qcol = lane & 15; c0.g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < AT_MAXT; ++j) attn_load_q(c0, min(wave + 4 * j, ((T + 15) >> 4) - 1), qf[j]);
+  }
   // ---- stage K and V (row-major, swizzled 128-B rows); rows >= T are zero ----
   // (all 18 loads of a thread are issued before the first LDS write: one trip to memory, not nine)
   constexpr int NLD = AT_KP * 8 / 256;                // 9 chunk pairs per thread
@@ -50,100 +178,33 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const s16x8 kv = key < T ? kreg[it] : z, vv = key < T ? vreg[it] : z;
     *reinterpret_cast<s16x8*>(Ks + tile_off(key, ch)) = kv;
-    *reinterpret_cast<s16x8*>(Vs + tile_off(key, ch)) = vv;
+    *reinterpret_cast<s16x8*>(Vs + vtile_off(key, ch)) = vv;
   }
   __syncthreads();
 
   const int qcol = lane & 15, g = lane >> 4;
   const int ntile = (T + 15) >> 4;
-  float npad = 0.f;                       // padded keys among this lane's keys {16kb + 4g + e}
-  for (int kb = T >> 4; kb < AT_KP / 16; ++kb)
-    for (int e = 0; e < 4; ++e) npad += (16 * kb + 4 * g + e >= T) ? 1.f : 0.f;
-  for (int qt = wave; qt < ntile; qt += 4) {
-    const int q0 = qt * 16;
-    const int qrow = min(q0 + qcol, T - 1);
-    // Q^T fragments (B operand): lane (query = lane&15, group g) holds Q[query][32s + 8g .. +7]
-    bf16x8 bq[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      bq[s] = *reinterpret_cast<const bf16x8*>(qb + qrow * tok_stride + 32 * s + 8 * g);
 
-    // ---- S^T = K Q^T: 18 key blocks; C/D: col = query (lane&15), row = key 4g+e of the block ----
-    f32x4 sacc[AT_KP / 16];
-#pragma unroll
-    for (int kb = 0; kb < AT_KP / 16; ++kb) {
-      sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 a = lds_frag(Ks, 16 * kb + qcol, g + 4 * s);
-        sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[s], sacc[kb], 0, 0, 0);
-      }
-      if ((kb % 3) == 2) __builtin_amdgcn_sched_barrier(0);   // keep at most 6 K fragments in flight
-    }
+  AttnCtx cx;
+  cx.Ks = Ks; cx.Vs = Vs; cx.qb = qb; cx.tok_stride = tok_stride; cx.T = T; cx.qcol = qcol; cx.g = g;
+  cx.trq = (lane & 15) >> 2; cx.trp = lane & 3; cx.scale_log2e = scale_log2e;
+  cx.out = out + (long long)b * T * H * AT_D + (long long)h * AT_D; cx.out_stride = (long long)H * AT_D;
 
-    // ---- softmax over keys, base 2: p = exp2((s - max) * scale*log2e) = exp2(fma(s, c, -max*c)).
-    // No masking: padded K rows are zero, so padded keys score exactly 0; they may only raise the
-    // stabiliser (still an upper bound of the row), their V rows are zero (no PV contribution),
-    // and their exp2(-max*c) terms are subtracted from the row sum (npad of them in this lane). ----
-    float mx = sacc[0][0];
+  // Software pipeline over this wave's query tiles (qt = wave, wave+4, ...), one score buffer:
+  //   phase 1: exp/convert of the CURRENT tile (VALU) interleaved with the QK^T MFMAs of the NEXT
+  //   phase 2: PV MFMAs of the current tile interleaved with the row max of the next (VALU)
+  f32x4 sc[AT_KP / 16];
+  bf16x8 pb[AT_KP / 32];
+  if (wave >= ntile) return;
+  attn_qk_all(cx, qf[0], sc);
+  float mx = attn_rowmax(sc);
 #pragma unroll
-    for (int kb = 0; kb < AT_KP / 16; ++kb)
-      mx = fmaxf(fmaxf(mx, fmaxf(sacc[kb][0], sacc[kb][1])), fmaxf(sacc[kb][2], sacc[kb][3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float nm = -mx * scale_log2e;
-    float sum = 0.f;
-    bf16x8 pb[AT_KP / 32];      // P^T as B operands: k-step t packs key blocks 2t (j<4) and 2t+1 (j>=4)
-#pragma unroll
-    for (int t = 0; t < AT_KP / 32; ++t) {
-      float p[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p[e] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * t][e], scale_log2e, nm));
-        p[4 + e] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * t + 1][e], scale_log2e, nm));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { sum += p[j]; pb[t][j] = (__bf16)p[j]; }
-    }
-    sum -= npad * __builtin_amdgcn_exp2f(nm);
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-
-    // ---- O^T = V^T P^T: 4 blocks of 16 output dims; A = V^T (row = dim, k = keys in P's order).
-    // ds_read_b64_tr_b16 per 16-lane group: lane 4q+p supplies the address of row (key) k0+q,
-    // columns (dims) 4p..4p+3, and receives column (dim) `lane&15` of the 4 rows — i.e. keys
-    // k0..k0+3 for its dim: elements j=0..3 (block 2t, k0 = 32t+4g) and j=4..7 (block 2t+1).
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-    const int trq = (lane & 15) >> 2, trp = lane & 3;
-    f32x4 oacc[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < AT_KP / 32; ++t) {
-        const int r0 = 32 * t + 4 * g + trq;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(Vs + tile_off(r0, 2 * db + (trp >> 1)) + 8 * (trp & 1)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(Vs + tile_off(r0 + 16, 2 * db + (trp >> 1)) + 8 * (trp & 1)));
-        const s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), pb[t], oacc[db], 0, 0, 0);
-        if ((t % 3) == 2) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // C/D: col = query (lane&15), row = dim 16db + 4g + e  -> 8-byte stores of 4 consecutive dims
-    if (q0 + qcol < T) {
-      uint16_t* orow = out + ((long long)b * T + q0 + qcol) * H * AT_D + (long long)h * AT_D;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        ushort4 o;
-        o.x = f32_to_bf16_bits(oacc[db][0] * inv);
-        o.y = f32_to_bf16_bits(oacc[db][1] * inv);
-        o.z = f32_to_bf16_bits(oacc[db][2] * inv);
-        o.w = f32_to_bf16_bits(oacc[db][3] * inv);
-        *reinterpret_cast<ushort4*>(orow + 16 * db + 4 * g) = o;
-      }
+  for (int j = 0; j < AT_MAXT; ++j) {
+    const int qt = wave + 4 * j;
+    if (qt < ntile) {   // wave-uniform
+      const bool has_next = qt + 4 < ntile;
+      const float ppad = attn_phase1(cx, sc, mx, pb, has_next, qf[j + 1 < AT_MAXT ? j + 1 : j]);
+      mx = attn_phase2(cx, pb, ppad, qt, has_next, sc);
     }
   }
 }
