@@ -15,17 +15,21 @@
 
 namespace vpr {
 
+struct GemmGroup { GemmProblem p[GEMM_MAX_GROUP]; int count; };
+
 template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
-    const uint16_t* __restrict__ A, int lda, int a_group_rows, long long a_group_stride,
-    const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int relu,
-    void* __restrict__ Cout, int ldc, int out_is_bf16, int M, int N, int K,
-    int tiles_m, int tiles_n) {
+__device__ __forceinline__ void gemm_nt_tile(const GemmProblem& pr, int orig, char* smem) {
   constexpr int BM = 128;
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * TILE_ROW_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint16_t* __restrict__ A = pr.A;
+  const uint16_t* __restrict__ W = pr.W;
+  const float* __restrict__ bias = pr.bias;
+  void* __restrict__ Cout = pr.C;
+  const int lda = pr.lda, a_group_rows = pr.a_group_rows, ldw = pr.ldw, relu = pr.relu, ldc = pr.ldc;
+  const long long a_group_stride = pr.a_group_stride;
+  const int out_is_bf16 = pr.out_is_bf16, M = pr.M, N = pr.N, K = pr.K, tiles_m = pr.tiles_m, tiles_n = pr.tiles_n;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   const int nwg = tiles_m * tiles_n;
   int tile;
   {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   const int tm = tile / tiles_n, tn = tile % tiles_n;
@@ -130,27 +134,74 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     }
 }
 
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem pr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_tile<BN, WM, WN>(pr, blockIdx.x, smem);
+}
+
+// Several independent small GEMMs in one launch (the SALAD layer-2 / token-MLP GEMMs are a few
+// tiles each: as separate launches each costs a full launch + K-loop latency with the chip idle).
+// Workgroup ids are dealt to the problems in order; every problem keeps its own XCD remap.
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_group_kernel(GemmGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int id = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+    if (i < grp.count) {
+      const int n = grp.p[i].tiles_m * grp.p[i].tiles_n;
+      if (id >= 0 && id < n) { gemm_nt_tile<BN, WM, WN>(grp.p[i], id, smem); id = -1; }
+      else if (id >= 0) id -= n;
+    }
+  }
+}
+
+static int gemm_check(const GemmProblem& g) {
+  if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return VPR_ERR_INVALID_ARG;
+  if (g.K % 64 != 0 || g.lda < g.K || g.ldw < g.K || g.ldc < g.N) return VPR_ERR_UNSUPPORTED;
+  if ((g.lda % 8) || (g.ldw % 8) || (g.a_group_rows > 0 && (g.a_group_stride % 8))) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.W)) & 15) return VPR_ERR_UNSUPPORTED;
+  return VPR_OK;
+}
+
 int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_group_stride,
                    const uint16_t* W, int ldw, const float* bias, int relu, void* C, int ldc,
                    int out_is_bf16, int M, int N, int K, hipStream_t stream) {
-  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VPR_ERR_INVALID_ARG;
-  if (K % 64 != 0 || lda < K || ldw < K || ldc < N) return VPR_ERR_UNSUPPORTED;
-  if ((lda % 8) || (ldw % 8) || (a_group_rows > 0 && (a_group_stride % 8))) return VPR_ERR_UNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return VPR_ERR_UNSUPPORTED;
-  const int tiles_m = (M + 127) / 128;
+  GemmProblem g{A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16, M, N, K, 0, 0};
+  const int st = gemm_check(g);
+  if (st != VPR_OK) return st;
+  g.tiles_m = (M + 127) / 128;
   if (N > 64) {
-    const int tiles_n = (N + 127) / 128;
+    g.tiles_n = (N + 127) / 128;
     constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
-    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
-                       A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
-                       M, N, K, tiles_m, tiles_n));
+    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g));
   } else {
-    const int tiles_n = 1;
+    g.tiles_n = 1;
     constexpr size_t lds = 2 * (128 + 64) * TILE_ROW_BYTES;
-    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<64, 4, 1>), dim3(tiles_m * tiles_n), dim3(256), lds, stream,
-                       A, lda, a_group_rows, a_group_stride, W, ldw, bias, relu, C, ldc, out_is_bf16,
-                       M, N, K, tiles_m, tiles_n));
+    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<64, 4, 1>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g));
   }
+  return VPR_OK;
+}
+
+// Grouped launch with 128x128 tiles for every member (a member with N <= 64 wastes MFMA work on
+// its half-empty tile, which is cheaper than a launch of its own).
+int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream) {
+  if (!probs || count < 1 || count > GEMM_MAX_GROUP) return VPR_ERR_INVALID_ARG;
+  GemmGroup grp;
+  grp.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    grp.p[i] = probs[i];
+    const int st = gemm_check(grp.p[i]);
+    if (st != VPR_OK) return st;
+    grp.p[i].tiles_m = (grp.p[i].M + 127) / 128;
+    grp.p[i].tiles_n = (grp.p[i].N + 127) / 128;
+    total += grp.p[i].tiles_m * grp.p[i].tiles_n;
+  }
+  for (int i = count; i < GEMM_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+  constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
+  VPR_TRY_LAUNCH(launch_kernel((gemm_nt_group_kernel<128, 2, 2>), dim3(total), dim3(256), lds, stream, grp));
   return VPR_OK;
 }
 

@@ -12,6 +12,16 @@ int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_gro
                    const uint16_t* W, int ldw, const float* bias, int relu, void* C, int ldc,
                    int out_is_bf16, int M, int N, int K, hipStream_t stream);
 
+// One member of a (grouped) GEMM launch: C = act(A W^T + bias); see gemm_nt.hip.  tiles_* are filled in
+// by the launcher.
+struct GemmProblem {
+  const uint16_t* A; int lda; int a_group_rows; long long a_group_stride;
+  const uint16_t* W; int ldw; const float* bias; int relu;
+  void* C; int ldc; int out_is_bf16; int M, N, K; int tiles_m, tiles_n;
+};
+constexpr int GEMM_MAX_GROUP = 3;
+int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
+
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
                               float* out_f32, uint16_t* out_bf16, hipStream_t stream);
