@@ -18,4 +18,8 @@ def timeit(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 for r in range(3):
-    print(f"sdpa {timeit(sdpa):.1f} us   hip {timeit(mine):.1f} us")
+    line = f"sdpa {timeit(sdpa):.1f} us"
+    for v in (0, 1, 2, 3):
+        os.environ["VPR_ATTN_VARIANT"] = str(v)
+        line += f"   v{v} {timeit(mine):.1f} us"
+    print(line)

@@ -9,8 +9,9 @@
 //        two 16-key blocks are packed into one 32-deep k-step; V sits row-major in LDS exactly
 //        like K and its transposed A fragments come from ds_read_b64_tr_b16, the gfx950
 //        hardware-transpose read: two 8-byte reads per MFMA, no transposed staging pass)
-// One workgroup (4 waves) per (image, head); each wave owns query tiles of 16 rows.
+// One workgroup (8 waves) per (image, head); each wave owns query tiles of 16 rows.
 // Input is the fused projection output qkv [B, T, 3, H, 64] (no q/k/v copies), output [B, T, H*64].
+#include <stdlib.h>
 #include "vpr_common.cuh"
 #include "vpr_internal.h"
 
@@ -18,7 +19,7 @@ namespace vpr {
 
 constexpr int AT_D = 64;          // head dim
 constexpr int AT_KP = 288;        // padded keys (18 blocks of 16 = 9 MFMA k-steps of 32)
-constexpr int AT_MAXT = 5;        // query tiles per wave: ceil(18 / 4)
+
 
 // V is only ever read through ds_read_b64_tr_b16; chunk c of key row r sits at c ^ (r & 7), which
 // makes every 32-lane half of those reads bank-conflict-free (the K swizzle would be 2-way).
@@ -138,7 +139,8 @@ __device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&p
   return mxn;
 }
 
-__global__ __launch_bounds__(256, 2) void attention_kernel(
+template <int NW, bool PIPE>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                                   // [AT_KP][64] bf16, swizzled 128-B rows
@@ -152,20 +154,22 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 
   // Q fragments of all of this wave's query tiles (qt = wave + 4j) are requested first, so their
   // latency hides under the K/V staging instead of stalling every tile.
+  constexpr int NT = NW * 64;
+  constexpr int AT_MAXT = (AT_KP / 16 + NW - 1) / NW;   // query tiles per wave
   bf16x8 qf[AT_MAXT][2];
   {
     AttnCtx c0;
     c0.qb = qb; c0.tok_stride = tok_stride; c0.T = T; c0.qcol = lane & 15; c0.g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < AT_MAXT; ++j) attn_load_q(c0, min(wave + 4 * j, ((T + 15) >> 4) - 1), qf[j]);
+    for (int j = 0; j < AT_MAXT; ++j) attn_load_q(c0, min(wave + NW * j, ((T + 15) >> 4) - 1), qf[j]);
   }
   // ---- stage K and V (row-major, swizzled 128-B rows); rows >= T are zero ----
   // (all 18 loads of a thread are issued before the first LDS write: one trip to memory, not nine)
-  constexpr int NLD = AT_KP * 8 / 256;                // 9 chunk pairs per thread
+  constexpr int NLD = (AT_KP * 8 + NT - 1) / NT;      // chunk pairs per thread (9 at 256 threads)
   s16x8 kreg[NLD], vreg[NLD];
 #pragma unroll
   for (int it = 0; it < NLD; ++it) {
-    const int i = tid + 256 * it;
+    const int i = min(tid + NT * it, AT_KP * 8 - 1);
     const int key = i >> 3, ch = i & 7;
     const int kc = key < T ? key : T - 1;               // clamp the address, zero the value below
     kreg[it] = *reinterpret_cast<const s16x8*>(kb_ + kc * tok_stride + ch * 8);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   }
 #pragma unroll
   for (int it = 0; it < NLD; ++it) {
-    const int i = tid + 256 * it;
+    const int i = min(tid + NT * it, AT_KP * 8 - 1);      // a clamped duplicate rewrites the same bytes
     const int key = i >> 3, ch = i & 7;
     const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const s16x8 kv = key < T ? kreg[it] : z, vv = key < T ? vreg[it] : z;
@@ -196,15 +200,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   f32x4 sc[AT_KP / 16];
   bf16x8 pb[AT_KP / 32];
   if (wave >= ntile) return;
-  attn_qk_all(cx, qf[0], sc);
-  float mx = attn_rowmax(sc);
+  if constexpr (PIPE) {
+    attn_qk_all(cx, qf[0], sc);
+    float mx = attn_rowmax(sc);
 #pragma unroll
-  for (int j = 0; j < AT_MAXT; ++j) {
-    const int qt = wave + 4 * j;
-    if (qt < ntile) {   // wave-uniform
-      const bool has_next = qt + 4 < ntile;
-      const float ppad = attn_phase1(cx, sc, mx, pb, has_next, qf[j + 1 < AT_MAXT ? j + 1 : j]);
-      mx = attn_phase2(cx, pb, ppad, qt, has_next, sc);
+    for (int j = 0; j < AT_MAXT; ++j) {
+      const int qt = wave + NW * j;
+      if (qt < ntile) {   // wave-uniform
+        const bool has_next = qt + NW < ntile;
+        const float ppad = attn_phase1(cx, sc, mx, pb, has_next, qf[j + 1 < AT_MAXT ? j + 1 : j]);
+        mx = attn_phase2(cx, pb, ppad, qt, has_next, sc);
+      }
+    }
+  } else {   // one tile at a time: fewer live registers, more waves per SIMD
+#pragma unroll
+    for (int j = 0; j < AT_MAXT; ++j) {
+      const int qt = wave + NW * j;
+      if (qt < ntile) {
+        attn_qk_all(cx, qf[j], sc);
+        const float mx = attn_rowmax(sc);
+        const float ppad = attn_phase1(cx, sc, mx, pb, false, qf[j]);
+        attn_phase2(cx, pb, ppad, qt, false, sc);
+      }
     }
   }
 }
@@ -220,14 +237,30 @@ extern "C" int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B,
   if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return VPR_ERR_INVALID_ARG;
   if (head_dim != AT_D || T > AT_KP || (long long)B * H > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) return VPR_ERR_UNSUPPORTED;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)AT_LDS) != hipSuccess)
-      return VPR_ERR_LAUNCH;
-    attr = true;
+  const char* venv = getenv("VPR_ATTN_VARIANT");      // A/B switch; 0 = default
+  const int variant = venv ? atoi(venv) : 0;
+  const float c = scale * 1.4426950408889634f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define VPR_ATTN_LAUNCH(NW, PIPE)                                                                        \
+  do {                                                                                                   \
+    static bool attr = false;                                                                            \
+    if (!attr) {                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NW, PIPE>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_LDS) != hipSuccess)    \
+        return VPR_ERR_LAUNCH;                                                                           \
+      attr = true;                                                                                       \
+    }                                                                                                    \
+    VPR_TRY_LAUNCH(launch_kernel(attention_kernel<NW, PIPE>, dim3((unsigned)(B * H)), dim3(NW * 64), AT_LDS, st, \
+                                 qkv, out, T, H, c));                                                    \
+  } while (0)
+  // Measured at B=64, T=257, H=16 (PyTorch SDPA: 94-99 us): 8 waves, one tile at a time, 128 VGPRs,
+  // 4 waves/SIMD: 37 us (default); 4 waves: 44 us; 4 waves software-pipelined across tiles
+  // (208 VGPRs, 2 waves/SIMD): 45 us — occupancy beats intra-wave overlap here.
+  switch (variant) {
+    case 1: VPR_ATTN_LAUNCH(4, false); break;
+    case 2: VPR_ATTN_LAUNCH(4, true); break;
+    default: VPR_ATTN_LAUNCH(8, false); break;
   }
-  VPR_TRY_LAUNCH(launch_kernel(attention_kernel, dim3((unsigned)(B * H)), dim3(256), AT_LDS,
-                               static_cast<hipStream_t>(stream), qkv, out, T, H, scale * 1.4426950408889634f));
+#undef VPR_ATTN_LAUNCH
   return VPR_OK;
 }
