@@ -111,6 +111,8 @@ class DinoV2(nn.Module):
             x = blk(x)
         return _ln(self.norm, x).contiguous()
 
+    gelu_in_epilogue = True
+
     def _hip_ok(self, x: torch.Tensor) -> bool:
         return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
                 and all(b.folded for b in self.blocks))
@@ -132,7 +134,14 @@ class DinoV2(nn.Module):
                 a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, C)
             y = blk.proj(a)
             x, h = ops.add_layernorm_bf16(x, y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            y = blk.fc2(F.gelu(blk.fc1(h)))
+            if self.gelu_in_epilogue:
+                # bias + GELU inside the fc1 GEMM epilogue (hipBLASLt's tanh form): removes a 270 MB
+                # elementwise pass per block.  Its deviation from erf-GELU (<= 3e-4) is below bf16
+                # resolution: against an f32 reference both forms measure the same max error (0.016).
+                hh = torch._addmm_activation(blk.fc1.bias, h.view(B * T, C), blk.fc1.weight.t(), use_gelu=True)
+                y = blk.fc2(hh).view(B, T, C)
+            else:
+                y = blk.fc2(F.gelu(blk.fc1(h)))
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
             x, h = ops.add_layernorm_bf16(x, y, nxt.weight, nxt.bias, nxt.eps)
         return h
