@@ -35,13 +35,15 @@ class HipEngine:
 
 
 def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
-    """Per-shard (vals, idx) [B,k] -> [world, B, k] on every rank (two small all-gathers)."""
+    """Per-shard (vals f32, idx i32) [B,k] -> [world, B, k] on every rank with ONE all-gather: the
+    two arrays travel as one int32 buffer [B, 2k] (values bit-cast), since at these sizes
+    (5 KB per rank) a collective costs its launch latency, not its bytes."""
     B, k = v.shape
-    vs = torch.empty((world * B, k), dtype=v.dtype, device=v.device)      # concatenated along dim 0:
-    is_ = torch.empty((world * B, k), dtype=i.dtype, device=i.device)     # the layout gloo and RCCL share
-    dist.all_gather_into_tensor(vs, v.contiguous(), group=group)
-    dist.all_gather_into_tensor(is_, i.contiguous(), group=group)
-    return vs.view(world, B, k), is_.view(world, B, k)
+    packed = torch.cat([v.contiguous().view(torch.int32), i.contiguous()], dim=1)          # [B, 2k] int32
+    out = torch.empty((world * B, 2 * k), dtype=torch.int32, device=v.device)              # concatenated along dim 0:
+    dist.all_gather_into_tensor(out, packed, group=group)                                   # the layout gloo and RCCL share
+    out = out.view(world, B, 2 * k)
+    return out[:, :, :k].contiguous().view(torch.float32), out[:, :, k:].contiguous()
 
 
 class ShardedGallery:
