@@ -815,7 +815,8 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
   int lev = 0;
   for (; lev < p.nlevel; ++lev) {
     // the fused final kernel takes over as soon as the candidates of a query fit one workgroup
-    if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 48 * 1024) break;
+    // (its LDS = 36 KB of select state + the query row, kept under the 64 KB default limit)
+    if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 24 * 1024) break;
     float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
     if (lev == 0)
@@ -828,7 +829,7 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
     L = p.nchunk[lev] * p.kp;
     ld = L;
   }
-  if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 48 * 1024) {
+  if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 24 * 1024) {
     if (o.fp8)
       VPR_TRY_LAUNCH(launch_kernel(knn_final_fused_kernel<true>, dim3(B), dim3(FF_NT), (size_t)rb, stream, cur_v,
                                    cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx));
