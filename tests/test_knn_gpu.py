@@ -34,6 +34,8 @@ def _check(dev, B, N, D, k, seed=0, index_base=0):
     (17, 12500, 1024, 10),     # one 8-way shard of the 100k gallery (rows), reduced D
     (300, 3000, 512, 10),      # >= 256 queries: the GEMM-shaped score path (all-gathered multi-GPU batch)
     (512, 12500, 128, 10),     # 8 ranks x 64 queries against one shard's rows
+    (3, 600, 16384, 5),        # rows wider than the fused final kernel's LDS budget: general rescore/order path
+    (2, 300000, 64, 64),       # > 4096 level-0 candidates per query: register select level + general path
 ])
 def test_knn_matches_oracle(dev, B, N, D, k):
     _check(dev, B, N, D, k)
