@@ -145,3 +145,47 @@ def test_config3_gallery_100k_sharded_8_ways(dev):
         vs.append(v), is_.append(i)
     vm, im = ops.topk_merge(torch.stack(vs), torch.stack(is_))
     assert torch.equal(im, i_all) and torch.equal(vm, v_all)
+
+
+def test_calculate_validation_scores_end_to_end(dev, tmp_path):
+    """The reference's entry point (dinov2salad_validation.py:55) on the MI355X path: image files +
+    label CSV + checkpoint in, de-normalised predictions and final_loss out; equals the same
+    stages called one by one (PIL resize -> normalise -> extractor -> HIP head -> scaler)."""
+    from PIL import Image
+    from vpr_amd import evaluate, modules, ops, postproc
+    from vpr_amd.preprocess import ResizeNormalize
+    rng = np.random.default_rng(0)
+    img_dir = tmp_path / "images_val"
+    img_dir.mkdir()
+    names, sizes = [f"img_{i:04d}.png" for i in range(7)], [(320, 240)] * 4 + [(200, 300)] * 3
+    for n, (w, h) in zip(names, sizes):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(img_dir / n)
+    import pandas as pd
+    df = pd.DataFrame({"filename": names + ["img_9999.png"], "timestamp": "12:00",
+                       "latitude": rng.normal(219658, 900, 8).round(), "longitude": rng.normal(143506, 1100, 8).round(),
+                       "angle": 0, "Region_ID": 1})
+    csv = tmp_path / "labels_val.csv"
+    df.to_csv(csv, index=False)
+    torch.manual_seed(3)
+    base = modules.DinoV2Salad("vit_small")
+    head_src = modules.DINOv2RegressionModel(torch.nn.Identity())
+    ck = tmp_path / "checkpoint_49_.pth"
+    sd = {("feature_extractor." + k): v for k, v in base.state_dict().items()}
+    sd.update(head_src.state_dict())
+    torch.save({"epoch": 49, "model_state_dict": sd}, ck)
+    res = evaluate.calculate_validation_scores(str(ck), str(csv), str(img_dir), base_model=base, batch_size=3, verbose=False)
+    assert res["preds"].shape == (7, 2) and res["filenames"] == names            # the missing file is dropped
+    # the same stages one by one
+    base = base.to(dev).to(torch.bfloat16).eval()
+    prep = ResizeNormalize(224, "bilinear", (0.5,) * 3, (0.5,) * 3, torch.bfloat16)
+    want = []
+    for n in names:
+        u8 = torch.from_numpy(np.array(Image.open(img_dir / n).convert("RGB"))[None]).to(dev)
+        desc = base(prep(u8))
+        r = head_src.regressor
+        want.append(ops.pose_head(desc, r[0].weight.to(dev), r[0].bias.to(dev), r[2].weight.to(dev), r[2].bias.to(dev)).cpu().numpy())
+    want = np.concatenate(want)
+    assert np.abs(res["preds_standardised"] - want).max() < 2e-3                  # batch composition only changes bf16 GEMM order
+    sc = postproc.LatLonScaler.campus()
+    assert np.array_equal(res["preds"], sc.inverse_transform(res["preds_standardised"]))
+    assert res["final_loss"] == pytest.approx(postproc.final_loss(res["preds"], res["targets"]))

@@ -1,0 +1,122 @@
+"""Drop-in evaluation entry points: same function name, arguments and printed/returned quantities as
+the reference's validation scripts, running on the MI355X path.
+
+  calculate_validation_scores(checkpoint_path, val_csv_path, image_dir)
+      dinov2salad/dinov2salad_validation.py:55-116   (DINOv2+SALAD descriptor -> MLP head -> lat/lon)
+  calculate_swin_validation_scores(checkpoint_path, val_csv_path, image_dir, preds_csv)
+      swin_transformer/swin_validation.py:48-134     (Swin pooler + Linear head, ID-sorted preds.csv)
+
+What differs from the reference loop: images are decoded on the host (PIL) but
+resized / normalised on the GPU (vpr_amd.preprocess, PIL-exact), batches stay on the device until
+the end (one D2H copy instead of one per batch), the model objects are passed in or built from a
+state dict instead of being fetched by name (torch.hub / from_pretrained need the network), and
+the scaler is a LatLonScaler (JSON or the campus constants) instead of a joblib pickle.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import pandas as pd
+import torch
+from PIL import Image
+
+from . import postproc, reports
+from .modules import DINOv2RegressionModel, DinoV2Salad, load_reference_checkpoint
+from .preprocess import HALF_MEAN, HALF_STD, IMAGENET_MEAN, IMAGENET_STD, ResizeNormalize
+
+
+def _existing_rows(val_csv_path: str, image_dir: str) -> pd.DataFrame:
+    val_df = pd.read_csv(val_csv_path)
+    filtered = val_df[val_df["filename"].apply(lambda x: os.path.exists(os.path.join(image_dir, x)))]
+    if len(val_df) != len(filtered):
+        print(f"Warning: {len(val_df) - len(filtered)} images listed in the validation CSV were not found in the image directory.")
+    return filtered.reset_index(drop=True)
+
+
+def _load_batch(image_dir: str, filenames, device) -> torch.Tensor:
+    """Decode a batch to uint8 [B,H,W,3] on the device (all images of a batch must share one size;
+    mixed sizes are handled by the caller batching per size)."""
+    arrs = [np.asarray(Image.open(os.path.join(image_dir, f)).convert("RGB")) for f in filenames]
+    return torch.from_numpy(np.stack(arrs)).to(device)
+
+
+def _batches_by_size(image_dir: str, filenames, batch_size: int):
+    """Yield (indices, filenames) groups of equal image size, in order of first appearance."""
+    sizes = {}
+    for i, f in enumerate(filenames):
+        with Image.open(os.path.join(image_dir, f)) as im:
+            sizes.setdefault(im.size, []).append(i)
+    for idxs in sizes.values():
+        for lo in range(0, len(idxs), batch_size):
+            sel = idxs[lo:lo + batch_size]
+            yield sel, [filenames[i] for i in sel]
+
+
+@torch.no_grad()
+def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_dir: str, *,
+                                base_model: Optional[DinoV2Salad] = None, arch: str = "vit_base",
+                                scaler: Optional[postproc.LatLonScaler] = None, batch_size: int = 16,
+                                device: str = "cuda", verbose: bool = True) -> dict:
+    df = _existing_rows(val_csv_path, image_dir)
+    dev = torch.device(device)
+    if base_model is None:
+        base_model = DinoV2Salad(arch)
+    base_model = base_model.to(dev).to(torch.bfloat16).eval()
+    model = DINOv2RegressionModel(base_model).to(dev)
+    load_reference_checkpoint(model, checkpoint_path)            # checkpoint['model_state_dict'] or a bare state dict
+    model.eval()
+    base_model.aggregator.pack()
+    scaler = scaler or postproc.LatLonScaler.campus()
+    prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)   # validation.py:18-22
+
+    filenames = df["filename"].tolist()
+    preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
+        x = prep(_load_batch(image_dir, names, dev))
+        preds_std[torch.tensor(idxs, device=dev)] = model(x)
+    all_preds = scaler.inverse_transform(preds_std.cpu().numpy())                  # fp32 in -> fp32 out (:84)
+    all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
+    final_loss = postproc.final_loss(all_preds, all_targets)                        # :101
+    if verbose:
+        print(all_preds.shape, all_targets.shape)
+        print(f"final_loss: {final_loss}")
+        print("\\nSample Predictions (Original Scale):")
+        for i in range(min(5, len(all_preds))):
+            (pl, po), (tl, to) = all_preds[i], all_targets[i]
+            print(f"Prediction: (Lat: {pl:.6f}, Lon: {po:.6f}), True: (Lat: {tl:.6f}, Lon: {to:.6f}), "
+                  f"Error: (Lat: {abs(pl - tl):.6f}, Lon: {abs(po - to):.6f})")
+    return {"final_loss": final_loss, "preds": all_preds, "targets": all_targets, "preds_standardised": preds_std.cpu().numpy(),
+            "filenames": filenames}
+
+
+@torch.no_grad()
+def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, preds_csv: Optional[str] = None, *,
+                                     checkpoint_path: Optional[str] = None, scaler: Optional[postproc.LatLonScaler] = None,
+                                     batch_size: int = 16, device: str = "cuda", verbose: bool = True) -> dict:
+    """`model`: a vpr_amd.modules.SwinRegressionModel (backbone object inside).  Preprocessing follows the
+    HF Swin image processor: bicubic resize to 224, /255, ImageNet mean/std."""
+    df = _existing_rows(val_csv_path, image_dir)
+    dev = torch.device(device)
+    model = model.to(dev).eval()
+    if checkpoint_path:
+        load_reference_checkpoint(model, checkpoint_path)
+    scaler = scaler or postproc.LatLonScaler.campus()
+    prep = ResizeNormalize(224, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
+    filenames = df["filename"].tolist()
+    preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
+        preds_std[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(image_dir, names, dev)))
+    all_preds = scaler.inverse_transform(preds_std.cpu().numpy())
+    all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
+    final_loss = postproc.final_loss(all_preds, all_targets)                        # swin_validation.py:100
+    if verbose:
+        print(all_preds.shape)
+        print(all_targets.shape)
+        print(f"final_loss: {final_loss}")
+    if preds_csv:
+        reports.write_id_sorted_preds(preds_csv, filenames, all_preds)              # :121-134
+        if verbose:
+            print("Saved predictions to preds.csv")
+    return {"final_loss": final_loss, "preds": all_preds, "targets": all_targets, "filenames": filenames}
