@@ -92,6 +92,13 @@ int vpr_gemm_nt_bf16(const uint16_t* A, int lda, int a_group_rows, long long a_g
                      const uint16_t* W, int ldw, const float* bias, int relu,
                      void* C, int ldc, int out_is_bf16, int M, int N, int K, void* stream);
 
+/* Same operation on 256 x 256 output tiles with LDS-DMA kept in flight across barriers (the
+ * large-M / large-N form: SALAD layer 1 is exactly 256 such tiles at B = 64).  Additional
+ * requirements: K >= 128, ldc % 4 == 0, C 16-byte aligned. */
+int vpr_gemm256_nt_bf16(const uint16_t* A, int lda, int a_group_rows, long long a_group_stride,
+                        const uint16_t* W, int ldw, const float* bias, int relu,
+                        void* C, int ldc, int out_is_bf16, int M, int N, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * kNN: cosine top-k of L2-normalised descriptors against a gallery shard.
  * Replaces: nothing in the reference tree (north-star addition between the

@@ -37,6 +37,8 @@ PROTOTYPES = {
                                              c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_gemm_nt_bf16": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p, c_int,
                                  c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vpr_gemm256_nt_bf16": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p, c_int,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vpr_knn_workspace_bytes": (c_size_t, [c_int] * 4),
     "vpr_knn_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),

@@ -21,6 +21,7 @@ struct GemmProblem {
 };
 constexpr int GEMM_MAX_GROUP = 3;
 int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
+int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,

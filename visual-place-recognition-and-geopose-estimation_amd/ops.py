@@ -127,7 +127,7 @@ def salad_sinkhorn_aggregate(scores: torch.Tensor, feats: torch.Tensor, tokfeat:
 
 
 def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-                 out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                 out_dtype: torch.dtype = torch.float32, tile256: bool = False) -> torch.Tensor:
     """act(a @ w.T + bias): a [M,K] bf16, w [N,K] bf16 -> [M,N] f32 or bf16 (MFMA, f32 accumulate)."""
     _need(a, torch.bfloat16, "a", 2)
     _need(w, torch.bfloat16, "w", 2)
@@ -140,9 +140,10 @@ def gemm_nt_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] 
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("gemm_nt_bf16: out_dtype must be float32 or bfloat16")
     out = torch.empty((M, N), dtype=out_dtype, device=a.device)
-    st = _lib.lib().vpr_gemm_nt_bf16(_ptr(a), K, 0, 0, _ptr(w), K, _ptr(bias), int(relu), _ptr(out), N,
-                                     int(out_dtype == torch.bfloat16), M, N, K, _stream())
-    _lib.check(st, "vpr_gemm_nt_bf16")
+    fn = _lib.lib().vpr_gemm256_nt_bf16 if tile256 else _lib.lib().vpr_gemm_nt_bf16
+    st = fn(_ptr(a), K, 0, 0, _ptr(w), K, _ptr(bias), int(relu), _ptr(out), N,
+            int(out_dtype == torch.bfloat16), M, N, K, _stream())
+    _lib.check(st, "vpr_gemm256_nt_bf16" if tile256 else "vpr_gemm_nt_bf16")
     return out
 
 
