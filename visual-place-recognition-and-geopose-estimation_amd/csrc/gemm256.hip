@@ -11,9 +11,11 @@
 //     A-late (phase 3).  Two K-tile buffers (128 KB LDS); a half-tile slot is refilled for K-tile
 //     kt+2 one phase after its last read, so five half-tiles (80 KB) are always in flight;
 //   * every thread issues exactly 2 LDS-DMA instructions per phase in a fixed order, so
-//     `s_waitcnt vmcnt(10)` (never 0 inside the loop) + one raw s_barrier retire exactly the
-//     half-tile the phase is about to read; past the last K-tile the same addresses are
-//     re-requested into slots nobody reads again, which keeps the count constant.
+//     `s_waitcnt vmcnt(10)` (never 0 inside the loop) + raw s_barriers retire exactly the
+//     half-tile the next phase is about to read; past the last K-tile the same addresses are
+//     re-requested (identical bytes), which keeps the count constant;
+//   * the two wave groups (wr = 0 / 1) run half a phase apart, so the MFMA cluster of one overlaps
+//     the LDS reads of the other on every SIMD.
 // Operand roles are swapped in the MFMA (A operand = W rows, B operand = A rows) so that a lane
 // ends up with 4 consecutive output columns: 8-byte bf16 / 16-byte f32 stores.
 #include "vpr_common.cuh"
@@ -44,7 +46,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int m0 = (tile / pr.tiles_n) * G2_BM, n0 = (tile % pr.tiles_n) * G2_BN;
+  // grouped raster inside the XCD's contiguous range: the ~32 tiles an XCD runs concurrently form
+  // a 4 (M) x 8 (N) patch, i.e. 12 operand panels through its L2 instead of 33 for a 1 x 32 strip
+  int tm, tn;
+  {
+    constexpr int GM = 4;
+    const int per_group = GM * pr.tiles_n;
+    const int grp = tile / per_group, in_grp = tile - grp * per_group;
+    const int first_m = grp * GM;
+    const int gsz = (pr.tiles_m - first_m) < GM ? (pr.tiles_m - first_m) : GM;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
 
   // ---- staging: this wave owns groups 2*wave, 2*wave+1 of each of the four half-tiles ----
   // index h: 0 = A-early, 1 = W-early, 2 = W-late, 3 = A-late
@@ -97,14 +111,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   issue(0, 1); issue(1, 1); issue(2, 1);
 
   const int frow = lane & 15, fch = lane >> 4;
+  // Two wave groups (wr = 0 / 1; each SIMD hosts one wave of each) run the same segment stream half
+  // a phase apart: every phase is  L {ds_read fragments, issue 2 LDS-DMA, retire next phase's data}
+  // | barrier | C {16 MFMAs} | barrier, and group 1 starts one barrier late, so one group's MFMA
+  // cluster overlaps the other's LDS reads on the same SIMD.  Hazards with the stagger:
+  //   RAW  the data a phase reads was retired (counted vmcnt) by EVERY wave at the end of its
+  //        previous L segment, which precedes a barrier both groups pass before either reads it;
+  //   WAR  a slot is refilled in the L segment after the one that read it, and every L segment
+  //        ends with lgkmcnt(0), so both groups' reads are complete two barriers earlier.
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A-early / W-early of K-tile 0 (before ANY barrier)
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const char* ta = smem + (kt & 1) * G2_BUF_BYTES;
     const char* tw = ta + G2_BM * TILE_ROW_BYTES;
     bf16x8 a[4][2], b0[2][2], b1[2][2];
 
     // ---- phase 1: A rows of quadrant-row 0, W rows of quadrant-col 0 ----
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -114,6 +137,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) a[rb][s] = lds_frag(ta, wr * 128 + rb * 16 + frow, fch + 4 * s);
     issue(3, kt + 1);
+    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires W-late(kt) for phase 2
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -123,15 +148,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
         for (int s = 0; s < 2; ++s)
           acc[0][0][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[cb][s], a[rb][s], acc[0][0][rb][cb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
 
     // ---- phase 2: W rows of quadrant-col 1 ----
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) b1[cb][s] = lds_frag(tw, wc * 64 + 32 + cb * 16 + frow, fch + 4 * s);
-    issue(0, kt + 2);          // A-early slot: every wave finished its phase-1 reads before this barrier
+    issue(0, kt + 2);          // A-early slot: both groups' phase-1 reads completed two barriers ago
+    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires A-late(kt) for phase 3
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -141,15 +167,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
         for (int s = 0; s < 2; ++s)
           acc[0][1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[cb][s], a[rb][s], acc[0][1][rb][cb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
 
     // ---- phase 3: A rows of quadrant-row 1 ----
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) a[rb][s] = lds_frag(ta, wr * 128 + 64 + rb * 16 + frow, fch + 4 * s);
     issue(1, kt + 2);          // W-early slot (read in phase 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -159,9 +186,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
         for (int s = 0; s < 2; ++s)
           acc[1][1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[cb][s], a[rb][s], acc[1][1][rb][cb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
 
     // ---- phase 4: no new operands (W quadrant-col 0 is still in registers) ----
-    issue(2, kt + 2);          // W-late slot: read in phase 2, and every wave has passed phase 3's barrier since
+    issue(2, kt + 2);          // W-late slot (read in phase 2)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              // retires A-early / W-early of K-tile kt+1
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -171,45 +201,85 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
         for (int s = 0; s < 2; ++s)
           acc[1][0][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[cb][s], a[rb][s], acc[1][0][rb][cb], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail before the workgroup exits
-
-  // ---- epilogue: C/D of (W-operand-as-A): row = n offset 4g+e, col = m (lane&15) ----
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // group 0 makes up the barrier group 1 spent at the start
+  // ---- epilogue ----
+  // C/D of (W-operand-as-A): a lane holds n = 4g+e (4 consecutive output columns) at row m = lane&15.
+  // Written straight to global that is 32-byte pieces scattered over 16 rows per store; instead the
+  // tile goes through the (now free) LDS in two 128-row passes and leaves as whole 512 B / 1 KB rows.
   const int g = lane >> 4;
+  float4 bias4[2][2];
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
+  for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = n0 + wc * 64 + qj * 32 + cb * 16 + 4 * g;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pr.bias != nullptr) {
+        if (n + 3 < N) b = *reinterpret_cast<const float4*>(pr.bias + n);
+        else {
+          if (n < N) b.x = pr.bias[n];
+          if (n + 1 < N) b.y = pr.bias[n + 1];
+          if (n + 2 < N) b.z = pr.bias[n + 2];
+        }
+      }
+      bias4[qj][cb] = b;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bias + the dummy tail of the LDS-DMA stream
+  __builtin_amdgcn_s_barrier();                      // nobody stages before every wave's DMA has landed
+  const int es = pr.out_is_bf16 ? 2 : 4;
+  const int pitch = G2_BN * es + 16;                 // +16 B: 16 rows of one column no longer share a bank
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      const int m = m0 + wr * 128 + qi * 64 + rb * 16 + (lane & 15);
-      if (m >= M) continue;
+      char* rowp = smem + (wr * 64 + rb * 16 + (lane & 15)) * pitch;
 #pragma unroll
       for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const int n = n0 + wc * 64 + qj * 32 + cb * 16 + 4 * g;
-          if (n >= N) continue;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[qi][qj][rb][cb][e] + (pr.bias != nullptr && n + e < N ? pr.bias[n + e] : 0.f);
-            if (pr.relu) v[e] = fmaxf(v[e], 0.f);
-          }
-          if (n + 3 < N) {
-            if (pr.out_is_bf16) {
-              ushort4 o;
-              o.x = f32_to_bf16_bits(v[0]); o.y = f32_to_bf16_bits(v[1]); o.z = f32_to_bf16_bits(v[2]); o.w = f32_to_bf16_bits(v[3]);
-              *reinterpret_cast<ushort4*>(reinterpret_cast<uint16_t*>(pr.C) + (long long)m * pr.ldc + n) = o;
-            } else {
-              *reinterpret_cast<float4*>(reinterpret_cast<float*>(pr.C) + (long long)m * pr.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+          const int nl = wc * 64 + qj * 32 + cb * 16 + 4 * g;
+          const float4 b = bias4[qj][cb];
+          float v0 = acc[qi][qj][rb][cb][0] + b.x, v1 = acc[qi][qj][rb][cb][1] + b.y;
+          float v2 = acc[qi][qj][rb][cb][2] + b.z, v3 = acc[qi][qj][rb][cb][3] + b.w;
+          if (pr.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+          if (pr.out_is_bf16) {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16);
+            o.y = (uint32_t)f32_to_bf16_bits(v2) | ((uint32_t)f32_to_bf16_bits(v3) << 16);
+            *reinterpret_cast<uint2*>(rowp + nl * 2) = o;
           } else {
-            for (int e = 0; e < 4 && n + e < N; ++e) {
-              if (pr.out_is_bf16) reinterpret_cast<uint16_t*>(pr.C)[(long long)m * pr.ldc + n + e] = f32_to_bf16_bits(v[e]);
-              else reinterpret_cast<float*>(pr.C)[(long long)m * pr.ldc + n + e] = v[e];
-            }
+            *reinterpret_cast<float4*>(rowp + nl * 4) = make_float4(v0, v1, v2, v3);
           }
         }
     }
+    __syncthreads();
+    // read-out: wave w owns staged rows 16w .. 16w+15; a row is 32 (bf16) or 64 (f32) 16-byte chunks
+    const int lanes_per_row = pr.out_is_bf16 ? 32 : 64;
+    const int rows_per_inst = 64 / lanes_per_row;
+    const int chunk = lane & (lanes_per_row - 1);
+    const int epc = 16 / es;                           // elements per chunk
+    const bool wide = ((pr.ldc * es) & 15) == 0;       // 16-byte row stores need a 16-byte row pitch
+    const int n = n0 + chunk * epc;
+    for (int i = 0; i < 16 / rows_per_inst; ++i) {
+      const int lr = wave * 16 + i * rows_per_inst + (pr.out_is_bf16 ? (lane >> 5) : 0);
+      const int m = m0 + (lr >> 6) * 128 + qi * 64 + (lr & 63);
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * pitch + chunk * 16);
+      if (m >= M || n >= N) continue;
+      char* dstp = reinterpret_cast<char*>(pr.C) + ((long long)m * pr.ldc + n) * es;
+      if (n + epc <= N && wide) {
+        *reinterpret_cast<uint4*>(dstp) = v;
+      } else {                                         // ragged last chunk of the row
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < epc && n + e < N; ++e) {
+          if (pr.out_is_bf16) reinterpret_cast<uint16_t*>(dstp)[e] = (uint16_t)(w4[e >> 1] >> (16 * (e & 1)));
+          else reinterpret_cast<uint32_t*>(dstp)[e] = w4[e];
+        }
+      }
+    }
+    if (qi == 0) __syncthreads();
+  }
 }
 
 int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
@@ -221,7 +291,7 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
     return VPR_ERR_UNSUPPORTED;
   g.tiles_m = (g.M + G2_BM - 1) / G2_BM;
   g.tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  constexpr size_t lds = 2 * (size_t)G2_BUF_BYTES;
+  constexpr size_t lds = 128 * (G2_BN * 4 + 16);   // >= the two K-tile buffers (128 KB); sized by the f32 epilogue staging
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
