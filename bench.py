@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="keep LayerScale as separate multiplies (A/B)")
     ap.add_argument("--no-tune", action="store_true", help="no hipBLASLt kernel autotune (TunableOp) in warm-up")
+    ap.add_argument("--no-resid-gemm", action="store_true", help="residual add fused into the LayerNorm instead of the proj/fc2 GEMM (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -125,6 +126,7 @@ def main():
             nn.init.normal_(p, std=0.02)
     ext_state = {k: v.clone() for k, v in ext32.state_dict().items()}
     ext = ext32.to(dev).to(torch.bfloat16)
+    ext.backbone.residual_in_gemm = not a.no_resid_gemm
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))

@@ -214,6 +214,12 @@ int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum
                            const void* beta, int params_are_bf16, float eps, uint16_t* y, long long M,
                            int C, void* stream);
 
+/* LayerNorm of (x + pre_bias): pre_bias [C] f32 is a per-column offset kept OUTSIDE the bf16 residual
+ * stream (the running sum of the proj / fc2 biases when the residual add lives in the GEMM, beta = 1).
+ * y = LayerNorm(f32(x) + pre_bias); x is not modified.  Constraints as vpr_layernorm_bf16; pre_bias 16-B aligned. */
+int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void* gamma, const void* beta,
+                            int params_are_bf16, float eps, uint16_t* y, long long M, int C, void* stream);
+
 /* Multi-head self-attention for short ViT sequences (backbone helper): softmax(q k^T * scale) v, non-causal.
  * qkv [B, T, 3, H, 64] bf16 (the fused projection output), out [B, T, H*64] bf16.  T <= 288, head_dim == 64. */
 int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,

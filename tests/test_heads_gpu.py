@@ -115,25 +115,54 @@ def test_add_layernorm_equals_add_then_layernorm(dev):
     assert torch.equal(y, ops.layernorm_bf16(x + r, gamma, beta, 1e-6))
 
 
-def test_backbone_hip_path_matches_block_loop(dev):
-    """DinoV2._forward_hip (fused add+LN) gives the same tokens as the plain block loop."""
+def test_bias_layernorm_matches_torch(dev):
+    """LayerNorm(f32(x) + pre_bias): the offset is added in f32 before the statistics."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(515, 1024, generator=g).to(torch.bfloat16)
+    pb = torch.randn(1024, generator=g) * 0.5
+    gamma = (1 + 0.1 * torch.randn(1024, generator=g)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(1024, generator=g)).to(torch.bfloat16)
+    ref = torch.nn.functional.layer_norm(x.float() + pb, (1024,), gamma.float(), beta.float(), 1e-6)
+    y = ops.bias_layernorm_bf16(x.to(dev), pb.to(dev), gamma.to(dev), beta.to(dev), 1e-6).cpu().float()
+    assert (y - ref).abs().max().item() < 0.02          # one bf16 rounding of values up to ~4
+    zero = ops.bias_layernorm_bf16(x.to(dev), torch.zeros(1024, device=dev), gamma.to(dev), beta.to(dev), 1e-6)
+    assert torch.equal(zero, ops.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6))
+
+
+@pytest.mark.parametrize("residual_in_gemm", [True, False])
+def test_backbone_hip_path_matches_block_loop(dev, residual_in_gemm):
+    """DinoV2._forward_hip (residual add inside the proj/fc2 GEMMs + deferred biases, or fused
+    add+LN) gives the same tokens as the plain block loop."""
     from vpr_amd.backbone import DinoV2
     torch.manual_seed(0)
     m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
+    m.residual_in_gemm = residual_in_gemm
     for b in m.blocks:
         torch.nn.init.normal_(b.ls1, std=0.3)
         torch.nn.init.normal_(b.ls2, std=0.3)
     m.fold_layerscale()
     x = torch.randn(3, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    import copy
+    m32 = copy.deepcopy(m).float()                     # same (bf16-rounded, LayerScale-folded) weights, f32 math
+
+    def block_loop(model, inp):
+        t = model.patch_embed(inp).flatten(2).transpose(1, 2)
+        t = torch.cat([model.cls_token.expand(3, -1, -1), t], dim=1) + model.pos_embed
+        for blk in model.blocks:
+            t = blk(t)
+        return torch.nn.functional.layer_norm(t.float(), (384,), model.norm.weight.float(), model.norm.bias.float(), 1e-6)
+
     with torch.no_grad():
         fast = m(x)
-        t = m.patch_embed(x).flatten(2).transpose(1, 2)
-        t = torch.cat([m.cls_token.expand(3, -1, -1), t], dim=1) + m.pos_embed
-        for blk in m.blocks:
-            t = blk(t)
-        slow = torch.nn.functional.layer_norm(t.float(), (384,), m.norm.weight.float(), m.norm.bias.float(), 1e-6)
+        slow = block_loop(m, x)                        # bf16 activations, PyTorch ops only
+        ref = block_loop(m32, x.float())               # f32 activations
     assert fast.shape == (3, 257, 384)
-    assert (fast.float() - slow).abs().max().item() < 0.06        # bf16 activations through 12 blocks
+    err_fast = (fast.float() - ref).abs().max().item()
+    err_slow = (slow - ref).abs().max().item()
+    # two bf16 pipelines differ from each other by up to the sum of their errors; judge each against f32:
+    # the HIP path must not be worse than the plain bf16 block loop (it rounds less often)
+    assert err_fast < max(0.06, 1.25 * err_slow), (err_fast, err_slow)
 
 
 @pytest.mark.parametrize("B,T,H", [(64, 257, 16), (2, 257, 6), (3, 100, 2), (1, 288, 1), (2, 17, 3)])

@@ -117,21 +117,40 @@ class DinoV2(nn.Module):
         return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
                 and all(b.folded for b in self.blocks))
 
+    residual_in_gemm = True
+
     def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
-        """Same math as the block loop with every residual add fused into the LayerNorm that
-        follows it (vpr_add_layernorm_bf16): x carries the residual stream, h the normalised copy."""
+        """Same math as the block loop, with x carrying the residual stream and h the normalised copy.
+        residual_in_gemm: the residual add lives in the proj / fc2 GEMM (`x.addmm_(a, W^T)`, beta = 1,
+        in place: the f32 accumulator is added to the stream before the single bf16 rounding) and
+        their biases are not written into the stream at all: the running sum of the biases is a
+        static [C] f32 vector per LayerNorm, added inside the kernel (vpr_bias_layernorm_bf16).
+        Per block that is LN r1 w1 twice (67 MB each) instead of add+LN r2 w2 (135 MB each), for
+        ~8 us of extra C reads in the two GEMMs.  Otherwise: every residual add fused into the
+        LayerNorm that follows it (vpr_add_layernorm_bf16)."""
         from . import ops
         B, T, C = x.shape
         x = x.contiguous()
         blocks = self.blocks
         h = ops.layernorm_bf16(x, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
         hip_attn = (C // blocks[0].heads == 64) and T <= 288      # the short-sequence HIP kernel's domain
+        if self.residual_in_gemm:
+            cum = self._cumulative_bias(x.device)
+            x2 = x.view(B * T, C)          # fresh tensor from forward(): safe to update in place
         for i, blk in enumerate(blocks):
             if hip_attn:
                 a = ops.attention_qkv_bf16(blk.qkv(h), blk.heads)
             else:
                 qkv = blk.qkv(h).view(B, T, 3, blk.heads, C // blk.heads).permute(2, 0, 3, 1, 4)
                 a = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, T, C)
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
+            if self.residual_in_gemm:
+                x2.addmm_(a.view(B * T, C), blk.proj.weight.t())
+                h = ops.bias_layernorm_bf16(x2, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+                hh = torch._addmm_activation(blk.fc1.bias, h, blk.fc1.weight.t(), use_gelu=True)
+                x2.addmm_(hh, blk.fc2.weight.t())
+                h = ops.bias_layernorm_bf16(x2, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps).view(B, T, C)
+                continue
             y = blk.proj(a)
             x, h = ops.add_layernorm_bf16(x, y, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             if self.gelu_in_epilogue:
@@ -142,9 +161,22 @@ class DinoV2(nn.Module):
                 y = blk.fc2(hh).view(B, T, C)
             else:
                 y = blk.fc2(F.gelu(blk.fc1(h)))
-            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
             x, h = ops.add_layernorm_bf16(x, y, nxt.weight, nxt.bias, nxt.eps)
-        return h
+        return h.view(B, T, C)
+
+    def _cumulative_bias(self, device: torch.device):
+        """cum[2i] = sum of proj/fc2 biases up to and including block i's proj; cum[2i+1] adds its fc2
+        (f32, one [2L, C] tensor; rebuilt when the biases change identity, e.g. after a state-dict load)."""
+        key = (str(device),) + tuple(b.proj.bias.data_ptr() for b in self.blocks) + tuple(b.proj.bias._version for b in self.blocks)
+        if getattr(self, "_cum_key", None) != key:
+            rows, acc = [], torch.zeros(self.embed_dim, dtype=torch.float32, device=device)
+            for blk in self.blocks:
+                acc = acc + blk.proj.bias.detach().float().to(device)
+                rows.append(acc)
+                acc = acc + blk.fc2.bias.detach().float().to(device)
+                rows.append(acc)
+            self._cum_bias, self._cum_key = torch.stack(rows).contiguous(), key
+        return self._cum_bias
 
     def fold_layerscale(self) -> "DinoV2":
         for blk in self.blocks:

@@ -14,7 +14,7 @@ namespace vpr {
 template <int NCH, typename ParamT>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ res, uint16_t* __restrict__ sum_out,
-    const ParamT* __restrict__ gamma, const ParamT* __restrict__ beta,
+    const float* __restrict__ pre_bias, const ParamT* __restrict__ gamma, const ParamT* __restrict__ beta,
     float eps, uint16_t* __restrict__ y, long long M, int C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long row = (long long)blockIdx.x * 4 + wave;
@@ -39,6 +39,12 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(
           s += v[i][e];
         }
         *reinterpret_cast<s16x8*>(sum_out + row * C + ch * 8) = o;
+      } else if (pre_bias != nullptr) {   // uniform: a per-column f32 offset carried outside the bf16 stream
+        const float4 p0 = *reinterpret_cast<const float4*>(pre_bias + ch * 8);
+        const float4 p1 = *reinterpret_cast<const float4*>(pre_bias + ch * 8 + 4);
+        const float pb[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[i][e] = bf16_bits_to_f32((uint16_t)q[e]) + pb[e]; s += v[i][e]; }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v[i][e] = bf16_bits_to_f32((uint16_t)q[e]); s += v[i][e]; }
@@ -81,15 +87,15 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(
 }
 
 template <typename ParamT>
-static int launch_ln(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const ParamT* g, const ParamT* b,
+static int launch_ln(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const float* pb, const ParamT* g, const ParamT* b,
                      float eps, uint16_t* y, long long M, int C, hipStream_t stream) {
   const dim3 grid((unsigned)((M + 3) / 4));
   const int nch = (C / 8 + 63) / 64;
   switch (nch) {
-    case 1: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<1, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, g, b, eps, y, M, C)); break;
-    case 2: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<2, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, g, b, eps, y, M, C)); break;
-    case 3: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<3, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, g, b, eps, y, M, C)); break;
-    case 4: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<4, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, g, b, eps, y, M, C)); break;
+    case 1: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<1, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
+    case 2: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<2, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
+    case 3: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<3, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
+    case 4: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<4, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
     default: return VPR_ERR_UNSUPPORTED;
   }
   return VPR_OK;
@@ -107,8 +113,8 @@ extern "C" int vpr_layernorm_bf16(const uint16_t* x, const void* gamma, const vo
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VPR_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (params_are_bf16)
-    return launch_ln<uint16_t>(x, nullptr, nullptr, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
-  return launch_ln<float>(x, nullptr, nullptr, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
+    return launch_ln<uint16_t>(x, nullptr, nullptr, nullptr, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
+  return launch_ln<float>(x, nullptr, nullptr, nullptr, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
 }
 
 extern "C" int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const void* gamma,
@@ -122,6 +128,19 @@ extern "C" int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, ui
     return VPR_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (params_are_bf16)
-    return launch_ln<uint16_t>(x, res, sum_out, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
-  return launch_ln<float>(x, res, sum_out, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
+    return launch_ln<uint16_t>(x, res, sum_out, nullptr, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
+  return launch_ln<float>(x, res, sum_out, nullptr, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
+}
+
+extern "C" int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void* gamma, const void* beta,
+                                       int params_are_bf16, float eps, uint16_t* y, long long M, int C, void* stream) {
+  if (!x || !pre_bias || !gamma || !beta || !y || M < 0 || C <= 0) return VPR_ERR_INVALID_ARG;
+  if (M == 0) return VPR_OK;
+  if ((C % 8) || C > 2048 || M > 0x1fffffffcLL) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pre_bias)) & 15)
+    return VPR_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (params_are_bf16)
+    return launch_ln<uint16_t>(x, nullptr, nullptr, pre_bias, static_cast<const uint16_t*>(gamma), static_cast<const uint16_t*>(beta), eps, y, M, C, s);
+  return launch_ln<float>(x, nullptr, nullptr, pre_bias, static_cast<const float*>(gamma), static_cast<const float*>(beta), eps, y, M, C, s);
 }

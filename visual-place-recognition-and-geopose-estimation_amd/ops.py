@@ -333,6 +333,26 @@ def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     return y
 
 
+def bias_layernorm_bf16(x: torch.Tensor, pre_bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                        eps: float) -> torch.Tensor:
+    """LayerNorm(f32(x) + pre_bias) -> bf16; pre_bias [C] f32 is added before the statistics."""
+    _need(x, torch.bfloat16, "x")
+    _need(pre_bias, torch.float32, "pre_bias", 1)
+    if gamma.dtype not in (torch.bfloat16, torch.float32) or beta.dtype != gamma.dtype:
+        raise RuntimeError("bias_layernorm_bf16: gamma/beta must both be bf16 or both f32")
+    _need(gamma, gamma.dtype, "gamma", 1)
+    _need(beta, beta.dtype, "beta", 1)
+    C = x.shape[-1]
+    if gamma.numel() != C or beta.numel() != C or pre_bias.numel() != C:
+        raise RuntimeError("bias_layernorm_bf16: parameter size")
+    y = torch.empty_like(x)
+    st = _lib.lib().vpr_bias_layernorm_bf16(_ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(beta),
+                                            int(gamma.dtype == torch.bfloat16), float(eps), _ptr(y),
+                                            x.numel() // C, C, _stream())
+    _lib.check(st, "vpr_bias_layernorm_bf16")
+    return y
+
+
 def add_layernorm_bf16(x: torch.Tensor, res: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                        eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """(x + res rounded to bf16, LayerNorm of that sum): the residual add fused into the next norm."""
