@@ -220,6 +220,13 @@ int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum
 int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void* gamma, const void* beta,
                             int params_are_bf16, float eps, uint16_t* y, long long M, int C, void* stream);
 
+/* Patch extraction for the ViT patch embedding (backbone helper; replaces the stride-P conv's im2col):
+ * images [B, Cin, H, W] bf16 -> out [B * (lead_rows + (H/P)*(W/P)), kpad] bf16,
+ * out[b*(lead+n) + lead + py*(W/P) + px][c*P*P + i*P + j] = images[b][c][py*P+i][px*P+j]; the lead_rows rows
+ * of every image and columns >= Cin*P*P are zero.  H % P == W % P == 0, W % 8 == 0, kpad % 8 == 0. */
+int vpr_patchify_bf16(const uint16_t* images, int B, int Cin, int H, int W, int patch, int kpad,
+                      int lead_rows, uint16_t* out, void* stream);
+
 /* Multi-head self-attention for short ViT sequences (backbone helper): softmax(q k^T * scale) v, non-causal.
  * qkv [B, T, 3, H, 64] bf16 (the fused projection output), out [B, T, H*64] bf16.  T <= 288, head_dim == 64. */
 int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,

@@ -115,6 +115,21 @@ def test_add_layernorm_equals_add_then_layernorm(dev):
     assert torch.equal(y, ops.layernorm_bf16(x + r, gamma, beta, 1e-6))
 
 
+@pytest.mark.parametrize("B,Cin,H,W,P,kpad,lead", [(3, 3, 224, 224, 14, 640, 1), (2, 3, 224, 224, 14, 592, 0),
+                                                    (1, 1, 32, 64, 8, 64, 2), (2, 3, 64, 32, 16, 768, 1)])
+def test_patchify_matches_unfold(dev, B, Cin, H, W, P, kpad, lead):
+    """Bit-exact vs F.unfold (the conv's im2col order c*P*P + i*P + j), zero cls rows and K padding."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, Cin, H, W, generator=g).to(torch.bfloat16)
+    out = ops.patchify_bf16(img.to(dev), P, kpad, lead).cpu()
+    n, K = (H // P) * (W // P), Cin * P * P
+    ref = torch.nn.functional.unfold(img.float(), P, stride=P).transpose(1, 2).to(torch.bfloat16)   # [B, n, K]
+    out = out.view(B, lead + n, kpad)
+    assert torch.equal(out[:, lead:, :K], ref)
+    assert not out[:, :lead].any() and not out[:, :, K:].any()
+
+
 def test_bias_layernorm_matches_torch(dev):
     """LayerNorm(f32(x) + pre_bias): the offset is added in f32 before the statistics."""
     from vpr_amd import ops
@@ -158,11 +173,30 @@ def test_backbone_hip_path_matches_block_loop(dev, residual_in_gemm):
         slow = block_loop(m, x)                        # bf16 activations, PyTorch ops only
         ref = block_loop(m32, x.float())               # f32 activations
     assert fast.shape == (3, 257, 384)
-    err_fast = (fast.float() - ref).abs().max().item()
-    err_slow = (slow - ref).abs().max().item()
     # two bf16 pipelines differ from each other by up to the sum of their errors; judge each against f32:
-    # the HIP path must not be worse than the plain bf16 block loop (it rounds less often)
-    assert err_fast < max(0.06, 1.25 * err_slow), (err_fast, err_slow)
+    # the HIP path must not be worse than the plain bf16 block loop (RMS: the max over 3e5 values is noise)
+    rms = lambda d: d.float().pow(2).mean().sqrt().item()
+    err_fast, err_slow = rms(fast.float() - ref), rms(slow - ref)
+    assert err_fast < 1.15 * err_slow and err_fast < 0.02 * rms(ref), (err_fast, err_slow, rms(ref))
+    assert (fast.float() - ref).abs().max().item() < 2.0 * (slow - ref).abs().max().item()
+
+
+def test_patch_embed_hip_matches_conv(dev):
+    """patchify + GEMM + static offsets == conv + cls cat + position add (to bf16 rounding of O(1) values)."""
+    from vpr_amd.backbone import DinoV2
+    torch.manual_seed(1)
+    m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
+    torch.nn.init.normal_(m.cls_token, std=0.5)
+    m.fold_layerscale()
+    x = torch.randn(2, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    assert m._hip_embed_ok(x)
+    with torch.no_grad():
+        raw, off = m._embed_hip(x)
+        got = raw.view(2, 257, 384).float() + off.float()
+        m32 = m.float()
+        t = m32.patch_embed(x.float()).flatten(2).transpose(1, 2)
+        ref = torch.cat([m32.cls_token.expand(2, -1, -1), t], dim=1) + m32.pos_embed
+    assert (got - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("B,T,H", [(64, 257, 16), (2, 257, 6), (3, 100, 2), (1, 288, 1), (2, 17, 3)])

@@ -62,6 +62,7 @@ PROTOTYPES = {
                                                 c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_longlong, c_int, c_void_p]),
     "vpr_bias_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_longlong, c_int, c_void_p]),
+    "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),
     "vpr_attention_qkv_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -10,6 +10,8 @@ layout vpr_salad_aggregate consumes directly (no permute to [B,C,16,16]).
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -103,6 +105,9 @@ class DinoV2(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous."""
+        if self._hip_embed_ok(x):
+            raw, offsets = self._embed_hip(x)
+            return self._forward_hip(raw.view(x.shape[0], 1 + self.num_patches, self.embed_dim), offsets)
         x = self.patch_embed(x).flatten(2).transpose(1, 2)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
         if self._hip_ok(x):
@@ -110,6 +115,42 @@ class DinoV2(nn.Module):
         for blk in self.blocks:
             x = blk(x)
         return _ln(self.norm, x).contiguous()
+
+    hip_patch_embed = True
+
+    def _hip_embed_ok(self, img: torch.Tensor) -> bool:
+        P = self.patch
+        return (self.hip_patch_embed and img.is_cuda and img.dtype == torch.bfloat16 and img.dim() == 4
+                and img.shape[2] % P == 0 and img.shape[3] % P == 0 and img.shape[3] % 8 == 0
+                and (img.shape[2] // P) * (img.shape[3] // P) == self.num_patches
+                and img.shape[1] * P * img.shape[3] * 2 <= 48 * 1024
+                and self.embed_dim % 8 == 0 and self.embed_dim <= 2048 and all(b.folded for b in self.blocks))
+
+    def _embed_hip(self, img: torch.Tensor):
+        """Patch embedding as patchify (HIP) + one library GEMM straight into the [B, 1+n, C] token
+        layout (the cls rows of A are zero), instead of MIOpen's implicit-GEMM conv + transposes +
+        cat + add (~270 us -> ~60 us at B = 64).  Returns (raw tokens, additive offsets): the offsets
+        (cls + pos[0] | pos[1+p] + conv bias, static per batch size) are added by the first LayerNorm
+        kernel, which writes the residual stream anyway."""
+        from . import ops
+        B, Cin = img.shape[0], img.shape[1]
+        P, C = self.patch, self.embed_dim
+        K = Cin * P * P
+        kpad = (K + 63) // 64 * 64
+        pe = self.patch_embed
+        key = (str(img.device), B, kpad, pe.weight.data_ptr(), pe.weight._version, pe.bias._version,
+               self.pos_embed.data_ptr(), self.pos_embed._version, self.cls_token._version)
+        if getattr(self, "_embed_key", None) != key:
+            w = torch.zeros((C, kpad), dtype=torch.bfloat16, device=img.device)
+            w[:, :K] = pe.weight.detach().reshape(C, K).to(img.device, torch.bfloat16)
+            pos = self.pos_embed.detach().float().to(img.device)[0]                    # [1+n, C]
+            off = pos.clone()
+            off[0] += self.cls_token.detach().float().to(img.device).view(C)
+            off[1:] += pe.bias.detach().float().to(img.device)
+            off = off.to(torch.bfloat16).unsqueeze(0).expand(B, -1, -1).contiguous()
+            self._embed_w, self._embed_off, self._embed_key = w, off, key
+        a = ops.patchify_bf16(img.contiguous(), P, kpad, 1)
+        return F.linear(a, self._embed_w), self._embed_off
 
     gelu_in_epilogue = True
 
@@ -119,7 +160,7 @@ class DinoV2(nn.Module):
 
     residual_in_gemm = True
 
-    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_hip(self, x: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same math as the block loop, with x carrying the residual stream and h the normalised copy.
         residual_in_gemm: the residual add lives in the proj / fc2 GEMM (`x.addmm_(a, W^T)`, beta = 1,
         in place: the f32 accumulator is added to the stream before the single bf16 rounding) and
@@ -132,7 +173,11 @@ class DinoV2(nn.Module):
         B, T, C = x.shape
         x = x.contiguous()
         blocks = self.blocks
-        h = ops.layernorm_bf16(x, blocks[0].norm1.weight, blocks[0].norm1.bias, blocks[0].norm1.eps)
+        n0 = blocks[0].norm1
+        if offsets is not None:            # tokens = raw patch GEMM + (cls | pos | conv bias), see _embed_hip
+            x, h = ops.add_layernorm_bf16(x, offsets, n0.weight, n0.bias, n0.eps)
+        else:
+            h = ops.layernorm_bf16(x, n0.weight, n0.bias, n0.eps)
         hip_attn = (C // blocks[0].heads == 64) and T <= 288      # the short-sequence HIP kernel's domain
         if self.residual_in_gemm:
             cum = self._cumulative_bias(x.device)

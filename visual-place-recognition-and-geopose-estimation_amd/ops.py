@@ -333,6 +333,18 @@ def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     return y
 
 
+def patchify_bf16(images: torch.Tensor, patch: int, kpad: int, lead_rows: int = 1) -> torch.Tensor:
+    """images [B, Cin, H, W] bf16 -> flattened patches [B * (lead_rows + n), kpad] bf16 in token order
+    (lead_rows zero rows per image for the cls slot; K zero-padded to kpad)."""
+    _need(images, torch.bfloat16, "images", 4)
+    B, Cin, H, W = images.shape
+    n = (H // patch) * (W // patch)
+    out = torch.empty((B * (lead_rows + n), kpad), dtype=torch.bfloat16, device=images.device)
+    st = _lib.lib().vpr_patchify_bf16(_ptr(images), B, Cin, H, W, int(patch), int(kpad), int(lead_rows), _ptr(out), _stream())
+    _lib.check(st, "vpr_patchify_bf16")
+    return out
+
+
 def bias_layernorm_bf16(x: torch.Tensor, pre_bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                         eps: float) -> torch.Tensor:
     """LayerNorm(f32(x) + pre_bias) -> bf16; pre_bias [C] f32 is added before the statistics."""
