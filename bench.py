@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="keep LayerScale as separate multiplies (A/B)")
     ap.add_argument("--no-tune", action="store_true", help="no hipBLASLt kernel autotune (TunableOp) in warm-up")
     ap.add_argument("--no-resid-gemm", action="store_true", help="residual add fused into the LayerNorm instead of the proj/fc2 GEMM (A/B)")
+    ap.add_argument("--no-split", action="store_true", help="backbone in the cls-first [B,257,C] row layout (M = 64.25 tile rows) instead of patch rows | cls rows (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -127,6 +128,7 @@ def main():
     ext_state = {k: v.clone() for k, v in ext32.state_dict().items()}
     ext = ext32.to(dev).to(torch.bfloat16)
     ext.backbone.residual_in_gemm = not a.no_resid_gemm
+    ext.backbone.hip_split = not a.no_split
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))
@@ -210,7 +212,7 @@ def main():
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n, r
         stages = {}
-        stages["backbone_ms"], tokens = stage_ms(lambda: ext.tokens(images))
+        stages["backbone_ms"], tokens = stage_ms(lambda: ext.backbone(images, split=True))
         stages["salad_ms"], (desc, desc16) = stage_ms(lambda: ext.aggregator(tokens, want_bf16=True))
         if world == 1:
             stages["knn_ms"], _ = stage_ms(lambda: ops.knn_topk(desc16, shard, a.k))

@@ -75,6 +75,15 @@ int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int
                         float* out_f32, uint16_t* out_bf16,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same aggregation with the patch tokens and the cls tokens in separate contiguous arrays (the layout
+ * the backbone computes in): patch_tokens [B, n, C] bf16, cls_tokens [B, C] bf16. */
+int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_tokens, int B,
+                              int patches_per_image, int C,
+                              const vpr_salad_weights* w, float dustbin,
+                              int m, int l, int t, int hidden, int sinkhorn_iters,
+                              float* out_f32, uint16_t* out_bf16,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Sinkhorn + aggregation stage alone (scores/features already computed) — exposed so tests can
  * pin it against closed-form known answers.
  * scores [B, n, m] f32 (token-major), feats [B, n, l] f32, tokfeat [B, t] f32 (un-normalised). */
@@ -231,6 +240,13 @@ int vpr_patchify_bf16(const uint16_t* images, int B, int Cin, int H, int W, int 
  * qkv [B, T, 3, H, 64] bf16 (the fused projection output), out [B, T, H*64] bf16.  T <= 288, head_dim == 64. */
 int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,
                            float scale, void* stream);
+
+/* Same attention on the "body rows first, tail rows last" token layout the backbone uses so that its
+ * GEMMs see M = B * body_tokens (an exact number of 256-row tiles at 256 patches per image):
+ * token t of image b is row b*body_tokens + t for t < body_tokens, else row
+ * tail_row0 + b*(T - body_tokens) + (t - body_tokens), in qkv [rows, 3, H, 64] and out [rows, H*64]. */
+int vpr_attention_qkv_split_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int body_tokens,
+                                 long long tail_row0, int H, int head_dim, float scale, void* stream);
 
 /* Utility: f32 -> bf16 (RNE) row copy, used to build galleries from f32 descriptors. */
 int vpr_f32_to_bf16(const float* src, uint16_t* dst, long long count, void* stream);

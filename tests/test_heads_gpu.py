@@ -145,14 +145,16 @@ def test_bias_layernorm_matches_torch(dev):
     assert torch.equal(zero, ops.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6))
 
 
-@pytest.mark.parametrize("residual_in_gemm", [True, False])
-def test_backbone_hip_path_matches_block_loop(dev, residual_in_gemm):
-    """DinoV2._forward_hip (residual add inside the proj/fc2 GEMMs + deferred biases, or fused
-    add+LN) gives the same tokens as the plain block loop."""
+@pytest.mark.parametrize("mode", ["split", "resid_gemm", "add_ln"])
+def test_backbone_hip_path_matches_block_loop(dev, mode):
+    """The HIP backbone paths (split row layout with patchify embedding; cls-first layout with the
+    residual add inside the proj/fc2 GEMMs + deferred biases; cls-first with fused add+LN) give the
+    same tokens as the plain block loop."""
     from vpr_amd.backbone import DinoV2
     torch.manual_seed(0)
     m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
-    m.residual_in_gemm = residual_in_gemm
+    m.hip_split = mode == "split"
+    m.residual_in_gemm = mode != "add_ln"
     for b in m.blocks:
         torch.nn.init.normal_(b.ls1, std=0.3)
         torch.nn.init.normal_(b.ls2, std=0.3)
@@ -183,20 +185,55 @@ def test_backbone_hip_path_matches_block_loop(dev, residual_in_gemm):
 
 def test_patch_embed_hip_matches_conv(dev):
     """patchify + GEMM + static offsets == conv + cls cat + position add (to bf16 rounding of O(1) values)."""
+    from vpr_amd import ops
     from vpr_amd.backbone import DinoV2
     torch.manual_seed(1)
     m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
     torch.nn.init.normal_(m.cls_token, std=0.5)
     m.fold_layerscale()
     x = torch.randn(2, 3, 224, 224, device=dev, dtype=torch.bfloat16)
-    assert m._hip_embed_ok(x)
+    assert m._hip_split_ok(x)
     with torch.no_grad():
-        raw, off = m._embed_hip(x)
-        got = raw.view(2, 257, 384).float() + off.float()
+        w, off = m._embed_consts(x)
+        raw = ops.patchify_bf16(x, 14, w.shape[1], 0) @ w.t()                       # [2*256, 384]
+        body = (raw.float() + off[:512].float()).view(2, 256, 384)
+        cls = off[512:].float()
         m32 = m.float()
         t = m32.patch_embed(x.float()).flatten(2).transpose(1, 2)
         ref = torch.cat([m32.cls_token.expand(2, -1, -1), t], dim=1) + m32.pos_embed
-    assert (got - ref).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
+    tol = 0.02 * max(1.0, ref.abs().max().item())
+    assert (body - ref[:, 1:]).abs().max().item() < tol and (cls - ref[:, 0]).abs().max().item() < tol
+
+
+def test_split_tokens_roundtrip_and_salad_split(dev):
+    """forward(split=True).joined() == forward(); SALAD on the pair == SALAD on the joined tensor (bit-exact:
+    same kernels, only the row addressing differs)."""
+    from vpr_amd.modules import DinoV2Salad
+    torch.manual_seed(2)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    x = torch.randn(3, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    st = ext.backbone(x, split=True)
+    assert st.patch.shape == (3, 256, 384) and st.cls.shape == (3, 384)
+    joined = ext.backbone(x)
+    assert torch.equal(joined, st.joined()) and torch.equal(joined[:, 0], st.cls)
+    d_split = ext.aggregator(st)
+    d_join = ext.aggregator(joined)
+    assert torch.equal(d_split, d_join)
+    assert torch.equal(ext(x), d_split)
+
+
+def test_attention_split_layout_matches_contiguous(dev):
+    """vpr_attention_qkv_split_bf16 on [patch rows | cls rows] == vpr_attention_qkv_bf16 on the same tokens cls-last."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, T, H = 5, 257, 6
+    qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * 1.5).to(torch.bfloat16).to(dev)     # token T-1 plays the cls role
+    ref = ops.attention_qkv_bf16(qkv, H)                                                       # [B, T, C]
+    split_in = torch.cat([qkv[:, :T - 1].reshape(B * (T - 1), -1), qkv[:, T - 1]], dim=0).contiguous()
+    out = ops.attention_qkv_split_bf16(split_in, B, T, T - 1, H)
+    assert torch.equal(out[:B * (T - 1)].view(B, T - 1, -1), ref[:, :T - 1])
+    assert torch.equal(out[B * (T - 1):], ref[:, T - 1])
 
 
 @pytest.mark.parametrize("B,T,H", [(64, 257, 16), (2, 257, 6), (3, 100, 2), (1, 288, 1), (2, 17, 3)])

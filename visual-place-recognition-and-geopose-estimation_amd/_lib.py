@@ -33,6 +33,9 @@ PROTOTYPES = {
     "vpr_salad_aggregate": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(SaladWeightsC), c_float,
                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "vpr_salad_aggregate_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(SaladWeightsC), c_float,
+                                          c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "vpr_salad_sinkhorn_aggregate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                              c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_gemm_nt_bf16": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p, c_int,
@@ -62,6 +65,7 @@ PROTOTYPES = {
                                                 c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_longlong, c_int, c_void_p]),
     "vpr_bias_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_longlong, c_int, c_void_p]),
+    "vpr_attention_qkv_split_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_int, c_int, c_float, c_void_p]),
     "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),

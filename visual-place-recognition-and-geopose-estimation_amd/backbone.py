@@ -10,7 +10,7 @@ layout vpr_salad_aggregate consumes directly (no permute to [B,C,16,16]).
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 import torch.nn as nn
@@ -46,6 +46,17 @@ def _ln(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
         from . import ops
         return ops.layernorm_bf16(x, norm.weight, norm.bias, norm.eps)
     return norm(x)
+
+
+class SplitTokens(NamedTuple):
+    """Final-norm tokens as the HIP backbone path holds them: patch [B, n, C] and cls [B, C], both
+    contiguous (vpr_salad_aggregate_split consumes the pair without a copy)."""
+    patch: torch.Tensor
+    cls: torch.Tensor
+
+    def joined(self) -> torch.Tensor:
+        """[B, 1+n, C], cls first (the reference / torch.hub layout)."""
+        return torch.cat([self.cls.unsqueeze(1), self.patch], dim=1)
 
 
 class Block(nn.Module):
@@ -103,54 +114,107 @@ class DinoV2(nn.Module):
         nn.init.normal_(self.cls_token, std=1e-6)
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous."""
-        if self._hip_embed_ok(x):
-            raw, offsets = self._embed_hip(x)
-            return self._forward_hip(raw.view(x.shape[0], 1 + self.num_patches, self.embed_dim), offsets)
+    def forward(self, x: torch.Tensor, split: bool = False):
+        """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous; with split=True a
+        SplitTokens(patch [B,n,C], cls [B,C]) pair (what the HIP path computes in; no copy)."""
+        if self._hip_split_ok(x):
+            st = self._forward_hip_split(x)
+            return st if split else st.joined()
         x = self.patch_embed(x).flatten(2).transpose(1, 2)
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
         if self._hip_ok(x):
-            return self._forward_hip(x)
-        for blk in self.blocks:
-            x = blk(x)
-        return _ln(self.norm, x).contiguous()
+            x = self._forward_hip(x)
+        else:
+            for blk in self.blocks:
+                x = blk(x)
+            x = _ln(self.norm, x).contiguous()
+        return SplitTokens(x[:, 1:].contiguous(), x[:, 0].contiguous()) if split else x
 
-    hip_patch_embed = True
+    hip_split = True
 
-    def _hip_embed_ok(self, img: torch.Tensor) -> bool:
-        P = self.patch
-        return (self.hip_patch_embed and img.is_cuda and img.dtype == torch.bfloat16 and img.dim() == 4
+    def _hip_split_ok(self, img: torch.Tensor) -> bool:
+        P, C = self.patch, self.embed_dim
+        return (self.hip_split and img.is_cuda and img.dtype == torch.bfloat16 and img.dim() == 4
                 and img.shape[2] % P == 0 and img.shape[3] % P == 0 and img.shape[3] % 8 == 0
                 and (img.shape[2] // P) * (img.shape[3] // P) == self.num_patches
                 and img.shape[1] * P * img.shape[3] * 2 <= 48 * 1024
-                and self.embed_dim % 8 == 0 and self.embed_dim <= 2048 and all(b.folded for b in self.blocks))
+                and C % 8 == 0 and C <= 2048 and C // self.blocks[0].heads == 64 and 1 + self.num_patches <= 288
+                and all(b.folded for b in self.blocks))
 
-    def _embed_hip(self, img: torch.Tensor):
-        """Patch embedding as patchify (HIP) + one library GEMM straight into the [B, 1+n, C] token
-        layout (the cls rows of A are zero), instead of MIOpen's implicit-GEMM conv + transposes +
-        cat + add (~270 us -> ~60 us at B = 64).  Returns (raw tokens, additive offsets): the offsets
-        (cls + pos[0] | pos[1+p] + conv bias, static per batch size) are added by the first LayerNorm
-        kernel, which writes the residual stream anyway."""
-        from . import ops
+    def _embed_consts(self, img: torch.Tensor):
+        """(patch-embedding weight [C, kpad] bf16, additive token offsets [B*n + B, C] bf16 in the
+        split row layout: pos[1+p] + conv bias for the patch rows, cls + pos[0] for the cls rows)."""
         B, Cin = img.shape[0], img.shape[1]
-        P, C = self.patch, self.embed_dim
+        P, C, n = self.patch, self.embed_dim, self.num_patches
         K = Cin * P * P
         kpad = (K + 63) // 64 * 64
         pe = self.patch_embed
         key = (str(img.device), B, kpad, pe.weight.data_ptr(), pe.weight._version, pe.bias._version,
                self.pos_embed.data_ptr(), self.pos_embed._version, self.cls_token._version)
         if getattr(self, "_embed_key", None) != key:
-            w = torch.zeros((C, kpad), dtype=torch.bfloat16, device=img.device)
-            w[:, :K] = pe.weight.detach().reshape(C, K).to(img.device, torch.bfloat16)
-            pos = self.pos_embed.detach().float().to(img.device)[0]                    # [1+n, C]
-            off = pos.clone()
-            off[0] += self.cls_token.detach().float().to(img.device).view(C)
-            off[1:] += pe.bias.detach().float().to(img.device)
-            off = off.to(torch.bfloat16).unsqueeze(0).expand(B, -1, -1).contiguous()
+            dev = img.device
+            w = torch.zeros((C, kpad), dtype=torch.bfloat16, device=dev)
+            w[:, :K] = pe.weight.detach().reshape(C, K).to(dev, torch.bfloat16)
+            pos = self.pos_embed.detach().float().to(dev)[0]                             # [1+n, C]
+            body = (pos[1:] + pe.bias.detach().float().to(dev)).to(torch.bfloat16)       # [n, C]
+            tail = (pos[0] + self.cls_token.detach().float().to(dev).view(C)).to(torch.bfloat16)
+            off = torch.cat([body.unsqueeze(0).expand(B, -1, -1).reshape(B * n, C),
+                             tail.unsqueeze(0).expand(B, -1)], dim=0).contiguous()
             self._embed_w, self._embed_off, self._embed_key = w, off, key
-        a = ops.patchify_bf16(img.contiguous(), P, kpad, 1)
-        return F.linear(a, self._embed_w), self._embed_off
+        return self._embed_w, self._embed_off
+
+    def _forward_hip_split(self, img: torch.Tensor) -> "SplitTokens":
+        """The whole backbone on the GPU in the split row layout [B*n patch rows | B cls rows]:
+        every linear layer runs as one library GEMM over the B*n patch rows — at n = 256 an exact
+        number of 256-row tiles (64 tile rows at B = 64; the cls-first [B, 257, C] layout gives 64.25,
+        i.e. a fourth, almost empty wave of tiles: hipBLASLt measures 88/117/96 us instead of
+        105/133/148 us for qkv/fc1/fc2) — plus a 64-row GEMM over the cls rows.
+        * patch embedding = HIP patchify + one GEMM (instead of MIOpen's implicit-GEMM conv +
+          transposes + cat + add); cls / position / conv-bias terms are a static additive matrix
+          consumed by the first LayerNorm kernel, which writes the residual stream anyway;
+        * the residual add lives in the proj / fc2 GEMM (`x.addmm_`, beta = 1, in place) and their
+          biases never enter the bf16 stream: their running sum is a static [C] f32 vector per
+          LayerNorm, added inside the kernel (vpr_bias_layernorm_bf16);
+        * bias + GELU in the fc1 GEMM epilogue (hipBLASLt's tanh form; vs an f32 reference the max
+          error equals erf-GELU's 0.016: bf16 rounding dominates);
+        * attention: vpr_attention_qkv_split_bf16 (token -> row mapping inside the kernel)."""
+        from . import ops
+        B, n, C, P = img.shape[0], self.num_patches, self.embed_dim, self.patch
+        Mp, M = B * n, B * n + B
+        dev, bf = img.device, torch.bfloat16
+        w, off = self._embed_consts(img)
+        a = ops.patchify_bf16(img.contiguous(), P, w.shape[1], 0)               # [Mp, kpad]
+        raw = torch.empty((M, C), dtype=bf, device=dev)
+        torch.mm(a, w.t(), out=raw[:Mp])
+        raw[Mp:].zero_()
+        blocks = self.blocks
+        n0 = blocks[0].norm1
+        x, h = ops.add_layernorm_bf16(raw, off, n0.weight, n0.bias, n0.eps)
+        cum = self._cumulative_bias(dev)
+
+        def linear(inp, lin, gelu=False):       # body rows and cls rows as two GEMMs into one buffer
+            out = torch.empty((M, lin.weight.shape[0]), dtype=bf, device=dev)
+            wt = lin.weight.t()
+            for lo, hi in ((0, Mp), (Mp, M)):
+                if gelu:
+                    torch._addmm_activation(lin.bias, inp[lo:hi], wt, use_gelu=True, out=out[lo:hi])
+                else:
+                    torch.addmm(lin.bias, inp[lo:hi], wt, out=out[lo:hi])
+            return out
+
+        def residual(inp, lin):
+            wt = lin.weight.t()
+            x[:Mp].addmm_(inp[:Mp], wt)
+            x[Mp:].addmm_(inp[Mp:], wt)
+
+        for i, blk in enumerate(blocks):
+            att = ops.attention_qkv_split_bf16(linear(h, blk.qkv), B, 1 + n, n, blk.heads)
+            residual(att, blk.proj)
+            h = ops.bias_layernorm_bf16(x, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            residual(linear(h, blk.fc1, gelu=True), blk.fc2)
+            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
+            h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
+        return SplitTokens(h[:Mp].view(B, n, C), h[Mp:])
 
     gelu_in_epilogue = True
 
@@ -160,7 +224,7 @@ class DinoV2(nn.Module):
 
     residual_in_gemm = True
 
-    def _forward_hip(self, x: torch.Tensor, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
         """Same math as the block loop, with x carrying the residual stream and h the normalised copy.
         residual_in_gemm: the residual add lives in the proj / fc2 GEMM (`x.addmm_(a, W^T)`, beta = 1,
         in place: the f32 accumulator is added to the stream before the single bf16 rounding) and
@@ -174,10 +238,7 @@ class DinoV2(nn.Module):
         x = x.contiguous()
         blocks = self.blocks
         n0 = blocks[0].norm1
-        if offsets is not None:            # tokens = raw patch GEMM + (cls | pos | conv bias), see _embed_hip
-            x, h = ops.add_layernorm_bf16(x, offsets, n0.weight, n0.bias, n0.eps)
-        else:
-            h = ops.layernorm_bf16(x, n0.weight, n0.bias, n0.eps)
+        h = ops.layernorm_bf16(x, n0.weight, n0.bias, n0.eps)
         hip_attn = (C // blocks[0].heads == 64) and T <= 288      # the short-sequence HIP kernel's domain
         if self.residual_in_gemm:
             cum = self._cumulative_bias(x.device)

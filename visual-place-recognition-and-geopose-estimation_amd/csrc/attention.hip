@@ -28,7 +28,11 @@ __device__ __forceinline__ int vtile_off(int row, int chunk) { return row * 128 
 struct AttnCtx {
   const char* Ks; const char* Vs; const uint16_t* qb; long long tok_stride; int T, qcol, g, trq, trp;
   float scale_log2e; uint16_t* out; long long out_stride;
+  long long row_base, tail_base; int Tp;   // token t of this image lives in row (t < Tp ? row_base + t : tail_base + t - Tp)
 };
+__device__ __forceinline__ long long attn_row(const AttnCtx& cx, int t) {
+  return t < cx.Tp ? cx.row_base + t : cx.tail_base + (t - cx.Tp);
+}
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // Q^T fragments (B operand) of query tile qt: lane (query = lane&15, group g) holds Q[query][32s + 8g .. +7]
@@ -36,7 +40,7 @@ __device__ __forceinline__ void attn_load_q(const AttnCtx& cx, int qt, bf16x8 (&
   const int qrow = min(qt * 16 + cx.qcol, cx.T - 1);
 #pragma unroll
   for (int s = 0; s < 2; ++s)
-    bq[s] = *reinterpret_cast<const bf16x8*>(cx.qb + qrow * cx.tok_stride + 32 * s + 8 * cx.g);
+    bq[s] = *reinterpret_cast<const bf16x8*>(cx.qb + attn_row(cx, qrow) * cx.tok_stride + 32 * s + 8 * cx.g);
 }
 // S^T block kb = K[16kb..16kb+15] Q^T; C/D: col = query (lane&15), row = key 4g+e of the block
 __device__ __forceinline__ f32x4 attn_qk_block(const AttnCtx& cx, int kb, const bf16x8 (&bq)[2]) {
@@ -125,7 +129,7 @@ __device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&p
   // C/D: col = query (lane&15), row = dim 16db + 4g + e  -> 8-byte stores of 4 consecutive dims
   const int q = qt * 16 + cx.qcol;
   if (q < cx.T) {
-    uint16_t* orow = cx.out + q * cx.out_stride;
+    uint16_t* orow = cx.out + attn_row(cx, q) * cx.out_stride;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       ushort4 o;
@@ -141,14 +145,15 @@ __device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&p
 
 template <int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
-    const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int H, float scale_log2e) {
+    const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int Tp, long long tail_row0, int H,
+    float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;                                                   // [AT_KP][64] bf16, swizzled 128-B rows
   char* Vs = smem + AT_KP * 128;                                     // [AT_KP][64] bf16, same layout
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long tok_stride = 3LL * H * AT_D;
-  const uint16_t* qb = qkv + (long long)b * T * tok_stride + (long long)h * AT_D;
+  const uint16_t* qb = qkv + (long long)h * AT_D;
   const uint16_t* kb_ = qb + (long long)H * AT_D;
   const uint16_t* vb = qb + 2LL * H * AT_D;
 
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
   {
     AttnCtx c0;
     c0.qb = qb; c0.tok_stride = tok_stride; c0.T = T; c0.qcol = lane & 15; c0.g = lane >> 4;
+    c0.Tp = Tp; c0.row_base = (long long)b * Tp; c0.tail_base = tail_row0 + (long long)b * (T - Tp);
 #pragma unroll
     for (int j = 0; j < AT_MAXT; ++j) attn_load_q(c0, min(wave + NW * j, ((T + 15) >> 4) - 1), qf[j]);
   }
@@ -172,8 +178,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
     const int i = min(tid + NT * it, AT_KP * 8 - 1);
     const int key = i >> 3, ch = i & 7;
     const int kc = key < T ? key : T - 1;               // clamp the address, zero the value below
-    kreg[it] = *reinterpret_cast<const s16x8*>(kb_ + kc * tok_stride + ch * 8);
-    vreg[it] = *reinterpret_cast<const s16x8*>(vb + kc * tok_stride + ch * 8);
+    const long long krow = kc < Tp ? (long long)b * Tp + kc : tail_row0 + (long long)b * (T - Tp) + (kc - Tp);
+    kreg[it] = *reinterpret_cast<const s16x8*>(kb_ + krow * tok_stride + ch * 8);
+    vreg[it] = *reinterpret_cast<const s16x8*>(vb + krow * tok_stride + ch * 8);
   }
 #pragma unroll
   for (int it = 0; it < NLD; ++it) {
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
   AttnCtx cx;
   cx.Ks = Ks; cx.Vs = Vs; cx.qb = qb; cx.tok_stride = tok_stride; cx.T = T; cx.qcol = qcol; cx.g = g;
   cx.trq = (lane & 15) >> 2; cx.trp = lane & 3; cx.scale_log2e = scale_log2e;
-  cx.out = out + (long long)b * T * H * AT_D + (long long)h * AT_D; cx.out_stride = (long long)H * AT_D;
+  cx.out = out + (long long)h * AT_D; cx.out_stride = (long long)H * AT_D;
+  cx.Tp = Tp; cx.row_base = (long long)b * Tp; cx.tail_base = tail_row0 + (long long)b * (T - Tp);
 
   // Software pipeline over this wave's query tiles (qt = wave, wave+4, ...), one score buffer:
   //   phase 1: exp/convert of the CURRENT tile (VALU) interleaved with the QK^T MFMAs of the NEXT
@@ -232,9 +240,9 @@ constexpr size_t AT_LDS = (size_t)2 * AT_KP * 128;
 
 using namespace vpr;
 
-extern "C" int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,
-                                      float scale, void* stream) {
-  if (!qkv || !out || B <= 0 || T <= 0 || H <= 0) return VPR_ERR_INVALID_ARG;
+static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, int Tp, long long tail_row0, int H,
+                            int head_dim, float scale, void* stream) {
+  if (!qkv || !out || B <= 0 || T <= 0 || H <= 0 || Tp < 0 || Tp > T || tail_row0 < 0) return VPR_ERR_INVALID_ARG;
   if (head_dim != AT_D || T > AT_KP || (long long)B * H > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) return VPR_ERR_UNSUPPORTED;
   const char* venv = getenv("VPR_ATTN_VARIANT");      // A/B switch; 0 = default
@@ -251,7 +259,7 @@ extern "C" int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B,
       attr = true;                                                                                       \
     }                                                                                                    \
     VPR_TRY_LAUNCH(launch_kernel(attention_kernel<NW, PIPE>, dim3((unsigned)(B * H)), dim3(NW * 64), AT_LDS, st, \
-                                 qkv, out, T, H, c));                                                    \
+                                 qkv, out, T, Tp, tail_row0, H, c));                                                    \
   } while (0)
   // Measured at B=64, T=257, H=16 (PyTorch SDPA: 94-99 us): 8 waves, one tile at a time, 128 VGPRs,
   // 4 waves/SIMD: 37 us (default); 4 waves: 44 us; 4 waves software-pipelined across tiles
@@ -263,4 +271,14 @@ extern "C" int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B,
   }
 #undef VPR_ATTN_LAUNCH
   return VPR_OK;
+}
+
+extern "C" int vpr_attention_qkv_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int H, int head_dim,
+                                      float scale, void* stream) {
+  return attention_launch(qkv, out, B, T, T, 0, H, head_dim, scale, stream);
+}
+
+extern "C" int vpr_attention_qkv_split_bf16(const uint16_t* qkv, uint16_t* out, int B, int T, int body_tokens,
+                                            long long tail_row0, int H, int head_dim, float scale, void* stream) {
+  return attention_launch(qkv, out, B, T, body_tokens, tail_row0, H, head_dim, scale, stream);
 }

@@ -255,17 +255,18 @@ extern "C" int vpr_salad_sinkhorn_aggregate(const float* scores, const float* fe
                                    out_f32, out_bf16, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
-                                   const vpr_salad_weights* w, float dustbin,
-                                   int m, int l, int t, int hidden, int sinkhorn_iters,
-                                   float* out_f32, uint16_t* out_bf16,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!tokens || !w || !out_f32 || !workspace || B <= 0 || tokens_per_image < 2 || C <= 0)
+// patch row r of image b at patch + b*patch_img_stride + r*C; cls token of image b at cls + b*cls_stride
+static int salad_run(const uint16_t* patch, long long patch_img_stride, const uint16_t* cls, long long cls_stride,
+                     int B, int n, int C, const vpr_salad_weights* w, float dustbin,
+                     int m, int l, int t, int hidden, int sinkhorn_iters,
+                     float* out_f32, uint16_t* out_bf16,
+                     void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!patch || !cls || !w || !out_f32 || !workspace || B <= 0 || n < 1 || C <= 0)
     return VPR_ERR_INVALID_ARG;
+  if ((patch_img_stride % 8) || (cls_stride % 8) || cls_stride > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
   if (!w->w1_sc || !w->b1_sc || !w->w2_s || !w->b2_s || !w->w2_c || !w->b2_c || !w->w1_t ||
       !w->b1_t || !w->w2_t || !w->b2_t)
     return VPR_ERR_INVALID_ARG;
-  const int n = tokens_per_image - 1;
   if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || (C % 64) || (hidden % 64))
     return VPR_ERR_UNSUPPORTED;
   SaladPlan p;
@@ -278,14 +279,13 @@ extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per
   float* F = reinterpret_cast<float*>(ws + p.off_F);
   uint16_t* Ht = reinterpret_cast<uint16_t*>(ws + p.off_Ht);
   float* g = reinterpret_cast<float*>(ws + p.off_g);
-  const long long img_stride = (long long)tokens_per_image * C;
   int st;
   // Launch 1: fused score+cluster layer 1 on the patch tokens (row r of image b at
   // tokens + b*img_stride + (1 + r)*C) together with token-MLP layer 1 on the cls tokens
   // (image b at tokens + b*img_stride).
   const GemmProblem l1[2] = {
-      {tokens + C, C, n, img_stride, w->w1_sc, C, w->b1_sc, 1, H, 2 * hidden, 1, B * n, 2 * hidden, C, 0, 0},
-      {tokens, (int)img_stride, 0, 0, w->w1_t, C, w->b1_t, 1, Ht, hidden, 1, B, hidden, C, 0, 0}};
+      {patch, C, n, patch_img_stride, w->w1_sc, C, w->b1_sc, 1, H, 2 * hidden, 1, B * n, 2 * hidden, C, 0, 0},
+      {cls, (int)cls_stride, 0, 0, w->w1_t, C, w->b1_t, 1, Ht, hidden, 1, B, hidden, C, 0, 0}};
   st = launch_gemm_nt_group(l1, 2, stream);
   if (st != VPR_OK) return st;
   // Launch 2: the three second layers (scores, cluster features, token features).
@@ -296,4 +296,26 @@ extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per
   st = launch_gemm_nt_group(l2, 3, stream);
   if (st != VPR_OK) return st;
   return launch_sinkhorn_aggregate(S, F, g, B, n, m, l, t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
+}
+
+extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
+                                   const vpr_salad_weights* w, float dustbin,
+                                   int m, int l, int t, int hidden, int sinkhorn_iters,
+                                   float* out_f32, uint16_t* out_bf16,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!tokens || tokens_per_image < 2 || C <= 0) return VPR_ERR_INVALID_ARG;
+  const long long img_stride = (long long)tokens_per_image * C;
+  return salad_run(tokens + C, img_stride, tokens, img_stride, B, tokens_per_image - 1, C, w, dustbin, m, l, t, hidden,
+                   sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_tokens, int B,
+                                         int patches_per_image, int C,
+                                         const vpr_salad_weights* w, float dustbin,
+                                         int m, int l, int t, int hidden, int sinkhorn_iters,
+                                         float* out_f32, uint16_t* out_bf16,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (patches_per_image < 1 || C <= 0) return VPR_ERR_INVALID_ARG;
+  return salad_run(patch_tokens, (long long)patches_per_image * C, cls_tokens, C, B, patches_per_image, C, w, dustbin,
+                   m, l, t, hidden, sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
 }

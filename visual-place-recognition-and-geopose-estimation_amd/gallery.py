@@ -93,7 +93,7 @@ def build_descriptors(extractor, image_batches: Iterable[torch.Tensor]) -> Tuple
     """Runs DinoV2Salad over batches of preprocessed images -> (f32 [N,8448], bf16 [N,8448]) on the GPU."""
     f32, b16 = [], []
     for images in image_batches:
-        d, d16 = extractor.aggregator(extractor.tokens(images), want_bf16=True)
+        d, d16 = extractor.features(images, want_bf16=True)
         f32.append(d), b16.append(d16)
     return torch.cat(f32), torch.cat(b16)
 

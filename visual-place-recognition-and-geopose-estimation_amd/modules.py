@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbone import DinoV2
+from .backbone import DinoV2, SplitTokens
 
 
 class SaladAggregator(nn.Module):
@@ -59,10 +59,14 @@ class SaladAggregator(nn.Module):
         return self._packed
 
     @torch.no_grad()
-    def forward(self, tokens: torch.Tensor, want_bf16: bool = False):
-        """tokens [B, 1+n, C] bf16 (cls first) -> descriptor [B, 8448] f32 (and a bf16 copy)."""
+    def forward(self, tokens, want_bf16: bool = False):
+        """tokens [B, 1+n, C] bf16 (cls first) or a backbone.SplitTokens pair -> descriptor [B, 8448] f32
+        (and a bf16 copy)."""
         w = self._packed or self.pack()
-        desc, desc16 = ops.salad_aggregate(tokens, w, 3, want_bf16)
+        if isinstance(tokens, SplitTokens):
+            desc, desc16 = ops.salad_aggregate_split(tokens.patch, tokens.cls, w, 3, want_bf16)
+        else:
+            desc, desc16 = ops.salad_aggregate(tokens, w, 3, want_bf16)
         return (desc, desc16) if want_bf16 else desc
 
 
@@ -76,12 +80,22 @@ class DinoV2Salad(nn.Module):
 
     @torch.no_grad()
     def tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """Final-norm tokens [B, 1+n, C] bf16, cls first (the hub model's layout)."""
         t = self.backbone(x)
         return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
 
     @torch.no_grad()
+    def features(self, x: torch.Tensor, want_bf16: bool = False):
+        """images -> descriptor (and its bf16 copy): backbone tokens stay in the layout the backbone
+        computed them in (SplitTokens on the HIP path), no re-layout copy before SALAD."""
+        t = self.backbone(x, split=True)
+        if t.patch.dtype != torch.bfloat16:
+            t = SplitTokens(t.patch.to(torch.bfloat16), t.cls.to(torch.bfloat16))
+        return self.aggregator(t, want_bf16=want_bf16)
+
+    @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.aggregator(self.tokens(x))
+        return self.features(x)
 
 
 def _mlp_head_args(seq: nn.Sequential):

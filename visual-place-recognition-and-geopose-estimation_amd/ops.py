@@ -106,6 +106,26 @@ def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int =
     return out, out16
 
 
+def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeights, sinkhorn_iters: int = 3,
+                          want_bf16: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """patch [B, n, C] bf16 + cls [B, C] bf16 -> (descriptor f32 [B, t+l*m], bf16 copy or None)."""
+    _need(patch, torch.bfloat16, "patch", 3)
+    _need(cls, torch.bfloat16, "cls", 2)
+    C, hidden, m, l, t = w.validate()
+    B, n, Ct = patch.shape
+    if Ct != C or tuple(cls.shape) != (B, C):
+        raise RuntimeError(f"patch {tuple(patch.shape)} / cls {tuple(cls.shape)} do not match weights with C={C}")
+    L = _lib.lib()
+    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), patch.device)
+    out = torch.empty((B, t + l * m), dtype=torch.float32, device=patch.device)
+    out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=patch.device) if want_bf16 else None
+    cw = w.c_struct()
+    st = L.vpr_salad_aggregate_split(_ptr(patch), _ptr(cls), B, n, C, ctypes.byref(cw), float(w.dustbin), m, l, t,
+                                     hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_salad_aggregate_split")
+    return out, out16
+
+
 def salad_sinkhorn_aggregate(scores: torch.Tensor, feats: torch.Tensor, tokfeat: torch.Tensor,
                              dustbin: float, sinkhorn_iters: int = 3,
                              want_bf16: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -395,4 +415,19 @@ def attention_qkv_bf16(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     out = torch.empty((B, T, C), dtype=torch.bfloat16, device=qkv.device)
     st = _lib.lib().vpr_attention_qkv_bf16(_ptr(qkv), _ptr(out), B, T, heads, 64, 0.125, _stream())
     _lib.check(st, "vpr_attention_qkv_bf16")
+    return out
+
+
+def attention_qkv_split_bf16(qkv: torch.Tensor, B: int, T: int, body_tokens: int, heads: int) -> torch.Tensor:
+    """Same attention on the backbone's split row layout: qkv [B*T, 3*H*64] with token t of image b in
+    row b*body_tokens + t (t < body_tokens) or B*body_tokens + b*(T-body_tokens) + (t-body_tokens)."""
+    _need(qkv, torch.bfloat16, "qkv", 2)
+    rows, C3 = qkv.shape
+    C = C3 // 3
+    if C3 != 3 * C or C % heads or C // heads != 64 or rows != B * T or not (0 <= body_tokens <= T):
+        raise RuntimeError("attention_qkv_split_bf16: needs head_dim 64 and a [B*T, 3*H*64] input")
+    out = torch.empty((rows, C), dtype=torch.bfloat16, device=qkv.device)
+    st = _lib.lib().vpr_attention_qkv_split_bf16(_ptr(qkv), _ptr(out), B, T, int(body_tokens), B * int(body_tokens),
+                                                 heads, 64, 0.125, _stream())
+    _lib.check(st, "vpr_attention_qkv_split_bf16")
     return out

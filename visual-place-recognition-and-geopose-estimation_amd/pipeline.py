@@ -32,8 +32,7 @@ class VPRGeoPosePipeline:
 
     @torch.no_grad()
     def step(self, images: torch.Tensor) -> StepOutput:
-        tokens = self.extractor.tokens(images)
-        desc, desc16 = self.extractor.aggregator(tokens, want_bf16=True)
+        desc, desc16 = self.extractor.features(images, want_bf16=True)
         g = self.gallery
         q_all = g.gather_queries(desc16)
         if self.knn_events is not None and g.world >= 1:
