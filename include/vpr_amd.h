@@ -229,6 +229,13 @@ int vpr_add_layernorm_bf16(const uint16_t* x, const uint16_t* res, uint16_t* sum
 int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void* gamma, const void* beta,
                             int params_are_bf16, float eps, uint16_t* y, long long M, int C, void* stream);
 
+/* Linear layer on a few rows (backbone helper: the cls-token rows of the split row layout):
+ * mode 0: out = in W^T + bias; mode 1: out = gelu_tanh(in W^T + bias); mode 2: out += in W^T (bf16 read-modify-write,
+ * bias unused).  in [M, K] bf16 (ldi), W [N, K] bf16 (ldw), bias [N] bf16 or f32, out [M, N] bf16 (ldo).
+ * K % 32 == 0, ldi/ldw % 8 == 0; f32 accumulation in a fixed order (deterministic). */
+int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+                           int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K, void* stream);
+
 /* Patch extraction for the ViT patch embedding (backbone helper; replaces the stride-P conv's im2col):
  * images [B, Cin, H, W] bf16 -> out [B * (lead_rows + (H/P)*(W/P)), kpad] bf16,
  * out[b*(lead+n) + lead + py*(W/P) + px][c*P*P + i*P + j] = images[b][c][py*P+i][px*P+j]; the lead_rows rows

@@ -77,3 +77,34 @@ def test_gemm256_repeatable_under_load(dev):
     assert (first - ref).abs().max().item() < 1e-3
     for _ in range(20):
         assert torch.equal(ops.gemm_nt_bf16(a, w, None, False, torch.float32, tile256=True), first)
+
+
+@pytest.mark.parametrize("M,N,K,mode,bias_f32", [(64, 3072, 1024, 0, False), (64, 4096, 1024, 1, False),
+                                                 (64, 1024, 4096, 2, False), (5, 40, 96, 0, True),
+                                                 (70, 1030, 640, 1, True), (3, 18, 32, 2, False)])
+def test_skinny_linear(dev, M, N, K, mode, bias_f32):
+    """The cls-row linear layer vs an f64 reference on the same bf16 operands (bias, tanh-GELU, in-place
+    accumulate); ragged M / N, more than 64 rows, an output that is a row slice of a wider buffer."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g)
+    b = b if bias_f32 else b.to(torch.bfloat16)
+    buf = torch.randn(M + 3, N, generator=g).to(torch.bfloat16)
+    acc = a.double() @ w.double().T
+    if mode == 0:
+        ref = acc + b.double()
+    elif mode == 1:
+        ref = torch.nn.functional.gelu(acc + b.double(), approximate="tanh")
+    else:
+        ref = buf[2:2 + M].double() + acc
+    dbuf = buf.to(dev)
+    ops.skinny_linear_bf16(a.to(dev), w.to(dev), None if mode == 2 else b.to(dev), dbuf[2:2 + M], mode)
+    got = dbuf.cpu()
+    assert torch.equal(got[:2], buf[:2]) and torch.equal(got[2 + M:], buf[2 + M:])          # neighbours untouched
+    err = (got[2:2 + M].double() - ref).abs().max().item()
+    assert err < 8e-3 * max(1.0, ref.abs().max().item())                                    # one bf16 rounding
+    again = buf.to(dev)
+    ops.skinny_linear_bf16(a.to(dev), w.to(dev), None if mode == 2 else b.to(dev), again[2:2 + M], mode)
+    assert torch.equal(again.cpu(), got)                                                     # deterministic

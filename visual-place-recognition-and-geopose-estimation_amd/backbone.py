@@ -192,26 +192,24 @@ class DinoV2(nn.Module):
         x, h = ops.add_layernorm_bf16(raw, off, n0.weight, n0.bias, n0.eps)
         cum = self._cumulative_bias(dev)
 
-        def linear(inp, lin, gelu=False):       # body rows and cls rows as two GEMMs into one buffer
-            out = torch.empty((M, lin.weight.shape[0]), dtype=bf, device=dev)
-            wt = lin.weight.t()
-            for lo, hi in ((0, Mp), (Mp, M)):
-                if gelu:
-                    torch._addmm_activation(lin.bias, inp[lo:hi], wt, use_gelu=True, out=out[lo:hi])
-                else:
-                    torch.addmm(lin.bias, inp[lo:hi], wt, out=out[lo:hi])
-            return out
-
-        def residual(inp, lin):
-            wt = lin.weight.t()
-            x[:Mp].addmm_(inp[:Mp], wt)
-            x[Mp:].addmm_(inp[Mp:], wt)
-
+        # patch rows: library GEMMs; cls rows: vpr_skinny_linear_bf16 (a library GEMM spends 9-14 us on 64
+        # rows).  proj keeps all B*n + B rows in one GEMM: its time does not depend on the tile remainder.
+        # (Tried: the cls-row kernels on a side stream, forked after each LayerNorm and joined before
+        # the next consumer — the cross-queue waits cost more than the ~5 us launches they hide:
+        # 12.8 vs 12.2 ms/step.)
         for i, blk in enumerate(blocks):
-            att = ops.attention_qkv_split_bf16(linear(h, blk.qkv), B, 1 + n, n, blk.heads)
-            residual(att, blk.proj)
+            C3, C4 = blk.qkv.weight.shape[0], blk.fc1.weight.shape[0]
+            qkv = torch.empty((M, C3), dtype=bf, device=dev)
+            ops.skinny_linear_bf16(h[Mp:], blk.qkv.weight, blk.qkv.bias, qkv[Mp:], 0)
+            torch.addmm(blk.qkv.bias, h[:Mp], blk.qkv.weight.t(), out=qkv[:Mp])
+            att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
+            x.addmm_(att, blk.proj.weight.t())
             h = ops.bias_layernorm_bf16(x, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            residual(linear(h, blk.fc1, gelu=True), blk.fc2)
+            hh = torch.empty((M, C4), dtype=bf, device=dev)
+            ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1)
+            torch._addmm_activation(blk.fc1.bias, h[:Mp], blk.fc1.weight.t(), use_gelu=True, out=hh[:Mp])
+            ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2)
+            x[:Mp].addmm_(hh[:Mp], blk.fc2.weight.t())
             nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
             h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
         return SplitTokens(h[:Mp].view(B, n, C), h[Mp:])

@@ -431,3 +431,25 @@ def attention_qkv_split_bf16(qkv: torch.Tensor, B: int, T: int, body_tokens: int
                                                  heads, 64, 0.125, _stream())
     _lib.check(st, "vpr_attention_qkv_split_bf16")
     return out
+
+
+def skinny_linear_bf16(inp: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+                       mode: int = 0) -> torch.Tensor:
+    """Linear layer on a few rows, written into `out` (a row slice of a larger buffer is fine):
+    mode 0 out = inp W^T + b; 1 gelu_tanh(inp W^T + b); 2 out += inp W^T."""
+    for t, name in ((inp, "inp"), (weight, "weight"), (out, "out")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"skinny_linear_bf16: {name} must be a GPU bf16 matrix with unit column stride")
+    M, K = inp.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or tuple(out.shape) != (M, N):
+        raise RuntimeError("skinny_linear_bf16: shape mismatch")
+    if mode != 2:
+        if bias is None or not bias.is_cuda or bias.numel() != N or bias.dtype not in (torch.bfloat16, torch.float32) \
+                or not bias.is_contiguous():
+            raise RuntimeError("skinny_linear_bf16: bias [N] bf16/f32 required")
+    st = _lib.lib().vpr_skinny_linear_bf16(_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias) if mode != 2 else None,
+                                           int(bias is not None and bias.dtype == torch.bfloat16), int(mode),
+                                           _ptr(out), out.stride(0), M, N, K, _stream())
+    _lib.check(st, "vpr_skinny_linear_bf16")
+    return out
