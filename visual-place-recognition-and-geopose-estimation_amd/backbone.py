@@ -193,8 +193,7 @@ class DinoV2(nn.Module):
         cum = self._cumulative_bias(dev)
 
         # patch rows: library GEMMs; cls rows: vpr_skinny_linear_bf16 (a library GEMM spends 9-14 us on 64
-        # rows).  proj keeps all B*n + B rows in one GEMM: its time does not depend on the tile remainder.
-        # (Tried: the cls-row kernels on a side stream, forked after each LayerNorm and joined before
+        # rows).  (Tried: proj over all B*n + B rows in one GEMM: 50 us vs 38 + 8; the cls-row kernels on a side stream, forked after each LayerNorm and joined before
         # the next consumer — the cross-queue waits cost more than the ~5 us launches they hide:
         # 12.8 vs 12.2 ms/step.)
         for i, blk in enumerate(blocks):
@@ -203,7 +202,8 @@ class DinoV2(nn.Module):
             ops.skinny_linear_bf16(h[Mp:], blk.qkv.weight, blk.qkv.bias, qkv[Mp:], 0)
             torch.addmm(blk.qkv.bias, h[:Mp], blk.qkv.weight.t(), out=qkv[:Mp])
             att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
-            x.addmm_(att, blk.proj.weight.t())
+            ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, x[Mp:], 2)
+            x[:Mp].addmm_(att[:Mp], blk.proj.weight.t())
             h = ops.bias_layernorm_bf16(x, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hh = torch.empty((M, C4), dtype=bf, device=dev)
             ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1)
