@@ -236,6 +236,27 @@ int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void
 int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
                            int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K, void* stream);
 
+/* vpr_bias_layernorm_bf16 over all M rows (-> y) AND, in the same launch, a linear layer on the LayerNorm of rows
+ * [cls_row0, cls_row0 + n_cls):  out[n_cls, N] = act(LN(x[cls rows] + pre_bias) W^T + b), act = identity or tanh-GELU,
+ * computed as  rstd * (x W'^T + cprime - mean * colsum) + bprime  on the raw rows, with the static per-layer operands
+ * W_scaled = W diag(gamma) [N, C] bf16, colsum[n] = sum_k W'[n,k], cprime = W' pre_bias, bprime = b + W beta (f32 [N]).
+ * row_stats [C/16, n_cls, 2] f32: (mean, centred sum of squares) of (cls rows + pre_bias) per 16-column block, as
+ * vpr_skinny_linear_stats_bf16 leaves them.  Saves the separate 64-row launch after each LayerNorm of the split
+ * row layout.  gamma/beta bf16, pre_bias f32 or NULL, C % 32 == 0, C <= 2048. */
+int vpr_bias_layernorm_cls_linear_bf16(const uint16_t* x, const float* pre_bias, const uint16_t* gamma,
+                                       const uint16_t* beta, float eps, uint16_t* y, long long M, int C,
+                                       long long cls_row0, int n_cls, const float* row_stats,
+                                       const uint16_t* W_scaled, int ldw, const float* colsum,
+                                       const float* cprime, const float* bprime, int gelu,
+                                       uint16_t* out, int ldo, int N, void* stream);
+
+/* vpr_skinny_linear_bf16 that also leaves, for every output row and 16-column block, the (mean, centred sum of
+ * squares) of bf16(out) + stats_bias in row_stats [N/16, M, 2] f32 (N % 16 == 0; stats_bias [N] f32 or NULL):
+ * the LayerNorm statistics of the rows it just wrote, for vpr_bias_layernorm_cls_linear_bf16. */
+int vpr_skinny_linear_stats_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+                                 int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
+                                 const float* stats_bias, float* row_stats, void* stream);
+
 /* Patch extraction for the ViT patch embedding (backbone helper; replaces the stride-P conv's im2col):
  * images [B, Cin, H, W] bf16 -> out [B * (lead_rows + (H/P)*(W/P)), kpad] bf16,
  * out[b*(lead+n) + lead + py*(W/P) + px][c*P*P + i*P + j] = images[b][c][py*P+i][px*P+j]; the lead_rows rows

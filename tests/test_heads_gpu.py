@@ -145,7 +145,47 @@ def test_bias_layernorm_matches_torch(dev):
     assert torch.equal(zero, ops.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6))
 
 
-@pytest.mark.parametrize("mode", ["split", "resid_gemm", "add_ln"])
+@pytest.mark.parametrize("gelu,C,N,n_cls,M", [(False, 1024, 3072, 64, 16448), (True, 1024, 4096, 64, 16448),
+                                                (False, 384, 1152, 3, 771), (True, 768, 72, 70, 500)])
+def test_bias_layernorm_cls_linear(dev, gelu, C, N, n_cls, M):
+    """The fused launch == vpr_bias_layernorm_bf16 on all rows (bit-exact) + the skinny linear on the
+    LayerNorm of the cls rows (same bf16 operands; tolerance = accumulation order + one bf16 rounding)."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(C + N)
+    x = (torch.randn(M, C, generator=g) * 2).to(torch.bfloat16).to(dev)
+    pb = (torch.randn(C, generator=g) * 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(torch.bfloat16).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, C, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    lb = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    row0 = M - n_cls
+    # the cls rows come out of a skinny accumulate that also leaves their statistics partials
+    prev_in = (torch.randn(n_cls, 64, generator=g)).to(torch.bfloat16).to(dev)
+    prev_w = (torch.randn(C, 64, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    rs = torch.empty((C // 16, n_cls, 2), dtype=torch.float32, device=dev)
+    ops.skinny_linear_bf16(prev_in, prev_w, None, x[row0:], 2, pb, rs)
+    v = x[row0:].float() + pb                                         # what the LayerNorm reads
+    blocks = v.view(n_cls, C // 16, 16)
+    assert torch.allclose(rs[:, :, 0].T, blocks.mean(-1), atol=1e-5)
+    assert torch.allclose(rs[:, :, 1].T, ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
+    out = torch.full((n_cls, N), 7.0, dtype=torch.bfloat16, device=dev)
+    consts = ops.ClsLinearConsts.build(w, lb, gamma, beta, pb)
+    y = ops.bias_layernorm_cls_linear_bf16(x, pb, gamma, beta, 1e-6, row0, rs, consts, out, gelu=gelu)
+    y_ref = ops.bias_layernorm_bf16(x, pb, gamma, beta, 1e-6)
+    assert torch.equal(y, y_ref)
+    # reference: the exact LayerNorm of the cls rows (f64) through the exact linear layer; the fused path rounds
+    # W*gamma to bf16 instead of the normalised activations: same size of error as the unfused path
+    ln = torch.nn.functional.layer_norm(v.double(), (C,), gamma.double(), beta.double(), 1e-6)
+    acc = ln @ w.double().T + lb.double()
+    ref = torch.nn.functional.gelu(acc, approximate="tanh") if gelu else acc
+    err = (out.double() - ref).abs().max().item()
+    unfused = y_ref[row0:].double() @ w.double().T + lb.double()
+    unfused = torch.nn.functional.gelu(unfused, approximate="tanh") if gelu else unfused
+    err_unfused = (unfused.to(torch.bfloat16).double() - ref).abs().max().item()
+    assert err < max(2.0 * err_unfused, 8e-3 * max(1.0, ref.abs().max().item())), (err, err_unfused)
+
+
+@pytest.mark.parametrize("mode", ["split", "split_unfused", "resid_gemm", "add_ln"])
 def test_backbone_hip_path_matches_block_loop(dev, mode):
     """The HIP backbone paths (split row layout with patchify embedding; cls-first layout with the
     residual add inside the proj/fc2 GEMMs + deferred biases; cls-first with fused add+LN) give the
@@ -153,7 +193,8 @@ def test_backbone_hip_path_matches_block_loop(dev, mode):
     from vpr_amd.backbone import DinoV2
     torch.manual_seed(0)
     m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
-    m.hip_split = mode == "split"
+    m.hip_split = mode.startswith("split")
+    m.fuse_ln_cls = mode == "split"
     m.residual_in_gemm = mode != "add_ln"
     for b in m.blocks:
         torch.nn.init.normal_(b.ls1, std=0.3)

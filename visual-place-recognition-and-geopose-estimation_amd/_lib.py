@@ -68,6 +68,11 @@ PROTOTYPES = {
     "vpr_attention_qkv_split_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_int, c_int, c_float, c_void_p]),
     "vpr_skinny_linear_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_int, c_int, c_int, c_void_p]),
+    "vpr_bias_layernorm_cls_linear_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_longlong,
+                                                   c_int, c_longlong, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "vpr_skinny_linear_stats_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                             c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),

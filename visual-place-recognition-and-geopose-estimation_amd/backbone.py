@@ -131,6 +131,7 @@ class DinoV2(nn.Module):
         return SplitTokens(x[:, 1:].contiguous(), x[:, 0].contiguous()) if split else x
 
     hip_split = True
+    fuse_ln_cls = False     # measured: 11.17/11.23 vs 11.22/11.26 ms per step — within noise, so the simpler path is the default
 
     def _hip_split_ok(self, img: torch.Tensor) -> bool:
         P, C = self.patch, self.embed_dim
@@ -196,22 +197,44 @@ class DinoV2(nn.Module):
         # rows).  (Tried: proj over all B*n + B rows in one GEMM: 50 us vs 38 + 8; the cls-row kernels on a side stream, forked after each LayerNorm and joined before
         # the next consumer — the cross-queue waits cost more than the ~5 us launches they hide:
         # 12.8 vs 12.2 ms/step.)
+        # fuse_ln_cls: the two cls-row linears that directly follow a LayerNorm (qkv, fc1) ride in the
+        # LayerNorm's launch (vpr_bias_layernorm_cls_linear_bf16).  The launch gets ~5 us longer, the
+        # separate 64-row launch was ~7.5 us: 0.03-0.05 ms per step, kept as an option only.
+        fuse = self.fuse_ln_cls and C % 32 == 0
+        rs = torch.empty((C // 16, B, 2), dtype=torch.float32, device=dev) if fuse else None   # stream-ordered reuse
+        fc = self._cls_fused_consts(dev) if fuse else None
+        C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
+        qkv = torch.empty((M, C3), dtype=bf, device=dev)
+        ops.skinny_linear_bf16(h[Mp:], blocks[0].qkv.weight, blocks[0].qkv.bias, qkv[Mp:], 0)
         for i, blk in enumerate(blocks):
-            C3, C4 = blk.qkv.weight.shape[0], blk.fc1.weight.shape[0]
-            qkv = torch.empty((M, C3), dtype=bf, device=dev)
-            ops.skinny_linear_bf16(h[Mp:], blk.qkv.weight, blk.qkv.bias, qkv[Mp:], 0)
             torch.addmm(blk.qkv.bias, h[:Mp], blk.qkv.weight.t(), out=qkv[:Mp])
             att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
-            ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, x[Mp:], 2)
+            ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, x[Mp:], 2, cum[2 * i] if fuse else None, rs)
             x[:Mp].addmm_(att[:Mp], blk.proj.weight.t())
-            h = ops.bias_layernorm_bf16(x, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hh = torch.empty((M, C4), dtype=bf, device=dev)
-            ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1)
+            n2 = blk.norm2
+            if fuse:
+                h = ops.bias_layernorm_cls_linear_bf16(x, cum[2 * i], n2.weight, n2.bias, n2.eps, Mp, rs,
+                                                       fc[2 * i + 1], hh[Mp:], gelu=True)
+            else:
+                h = ops.bias_layernorm_bf16(x, cum[2 * i], n2.weight, n2.bias, n2.eps)
+                ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1)
             torch._addmm_activation(blk.fc1.bias, h[:Mp], blk.fc1.weight.t(), use_gelu=True, out=hh[:Mp])
-            ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2)
+            last = i + 1 == len(blocks)
+            ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2,
+                                   cum[2 * i + 1] if fuse and not last else None, rs if not last else None)
             x[:Mp].addmm_(hh[:Mp], blk.fc2.weight.t())
-            nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else self.norm
-            h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
+            if i + 1 < len(blocks):
+                nb = blocks[i + 1]
+                qkv = torch.empty((M, C3), dtype=bf, device=dev)
+                if fuse:
+                    h = ops.bias_layernorm_cls_linear_bf16(x, cum[2 * i + 1], nb.norm1.weight, nb.norm1.bias, nb.norm1.eps,
+                                                           Mp, rs, fc[2 * i + 2], qkv[Mp:])
+                else:
+                    h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], nb.norm1.weight, nb.norm1.bias, nb.norm1.eps)
+                    ops.skinny_linear_bf16(h[Mp:], nb.qkv.weight, nb.qkv.bias, qkv[Mp:], 0)
+            else:
+                h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], self.norm.weight, self.norm.bias, self.norm.eps)
         return SplitTokens(h[:Mp].view(B, n, C), h[Mp:])
 
     gelu_in_epilogue = True
@@ -267,6 +290,24 @@ class DinoV2(nn.Module):
                 y = blk.fc2(F.gelu(blk.fc1(h)))
             x, h = ops.add_layernorm_bf16(x, y, nxt.weight, nxt.bias, nxt.eps)
         return h.view(B, T, C)
+
+    def _cls_fused_consts(self, device: torch.device):
+        """ClsLinearConsts of the LayerNorm-fused cls-row linears: entry 2i = block i's (norm1, qkv) with the
+        cumulative bias before it (entry 0 unused: block 0's first LayerNorm is the embedding add+LN), entry
+        2i+1 = block i's (norm2, fc1).  Static, rebuilt when the parameters change identity / version."""
+        from . import ops
+        ps = [p for b in self.blocks for p in (b.qkv.weight, b.qkv.bias, b.fc1.weight, b.fc1.bias, b.proj.bias, b.fc2.bias,
+                                               b.norm1.weight, b.norm1.bias, b.norm2.weight, b.norm2.bias)]
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_clsf_key", None) != key:
+            cum = self._cumulative_bias(device)
+            out = []
+            for i, b in enumerate(self.blocks):
+                out.append(None if i == 0 else
+                           ops.ClsLinearConsts.build(b.qkv.weight, b.qkv.bias, b.norm1.weight, b.norm1.bias, cum[2 * i - 1]))
+                out.append(ops.ClsLinearConsts.build(b.fc1.weight, b.fc1.bias, b.norm2.weight, b.norm2.bias, cum[2 * i]))
+            self._clsf, self._clsf_key = out, key
+        return self._clsf
 
     def _cumulative_bias(self, device: torch.device):
         """cum[2i] = sum of proj/fc2 biases up to and including block i's proj; cum[2i+1] adds its fc2

@@ -24,7 +24,8 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 template <typename BiasT, int NW, int MBW>
 __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
     const uint16_t* __restrict__ in, int ldi, const uint16_t* __restrict__ W, int ldw,
-    const BiasT* __restrict__ bias, int mode, uint16_t* __restrict__ out, int ldo, int M, int N, int K) {
+    const BiasT* __restrict__ bias, int mode, uint16_t* __restrict__ out, int ldo, int M, int N, int K,
+    const float* __restrict__ stats_bias, float* __restrict__ row_stats) {
   constexpr int UNR = MBW == 4 ? 4 : 8;          // K-steps per batch: (1 + MBW) * UNR fragment loads in flight
   __shared__ float red[NW][MBW][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,27 +72,53 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
     s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
   }
   const int m = m0 + wave * 16 + r, n = n0 + 4 * g;
-  if (m >= M || n >= N) return;
-  uint16_t* op = out + (long long)m * ldo + n;
+  const bool live = m < M && n < N;
+  uint16_t* op = out + (long long)min(m, M - 1) * ldo + min(n, N - 1);
   float v[4] = {s[0], s[1], s[2], s[3]};
+  uint16_t ob[4] = {0, 0, 0, 0};
+  if (live) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (n + e >= N) break;
-    if (mode == SK_ACCUMULATE) {
-      v[e] += bf16_bits_to_f32(op[e]);
+    for (int e = 0; e < 4; ++e) {
+      if (n + e >= N) break;
+      if (mode == SK_ACCUMULATE) {
+        v[e] += bf16_bits_to_f32(op[e]);
+      } else {
+        float b;
+        if constexpr (sizeof(BiasT) == 2) b = bf16_bits_to_f32((uint16_t)bias[n + e]); else b = bias[n + e];
+        v[e] += b;
+        if (mode == SK_BIAS_GELU) v[e] = gelu_tanh(v[e]);
+      }
+      ob[e] = f32_to_bf16_bits(v[e]);
+    }
+    if (n + 3 < N && (ldo & 3) == 0) {
+      ushort4 o;
+      o.x = ob[0]; o.y = ob[1]; o.z = ob[2]; o.w = ob[3];
+      *reinterpret_cast<ushort4*>(op) = o;
     } else {
-      float b;
-      if constexpr (sizeof(BiasT) == 2) b = bf16_bits_to_f32((uint16_t)bias[n + e]); else b = bias[n + e];
-      v[e] += b;
-      if (mode == SK_BIAS_GELU) v[e] = gelu_tanh(v[e]);
+      for (int e = 0; e < 4 && n + e < N; ++e) op[e] = ob[e];
     }
   }
-  if (n + 3 < N && (ldo & 3) == 0) {
-    ushort4 o;
-    o.x = f32_to_bf16_bits(v[0]); o.y = f32_to_bf16_bits(v[1]); o.z = f32_to_bf16_bits(v[2]); o.w = f32_to_bf16_bits(v[3]);
-    *reinterpret_cast<ushort4*>(op) = o;
-  } else {
-    for (int e = 0; e < 4 && n + e < N; ++e) op[e] = f32_to_bf16_bits(v[e]);
+  if (row_stats != nullptr) {
+    // (mean, centred sum of squares) of this row over the workgroup's 16 columns, of the values the next
+    // LayerNorm will read: bf16(out) + stats_bias.  The consumer merges the N/16 partials in a fixed
+    // order (Chan's formula), so the LayerNorm statistics cost it no pass over the rows.  N % 16 == 0.
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      t[e] = bf16_bits_to_f32(ob[e]) + (stats_bias != nullptr && n + e < N ? stats_bias[n + e] : 0.f);
+    float sm = (t[0] + t[1]) + (t[2] + t[3]);
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm * (1.0f / 16.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = t[e] - mean; m2 = fmaf(d, d, m2); }
+    m2 += __shfl_xor(m2, 16, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    if (g == 0 && m < M) {
+      float* dst = row_stats + ((long long)blockIdx.x * M + m) * 2;
+      dst[0] = mean; dst[1] = m2;
+    }
   }
 }
 
@@ -99,9 +126,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
 
 using namespace vpr;
 
-extern "C" int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
-                                      int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
-                                      void* stream) {
+static int skinny_launch(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+                         int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
+                         const float* stats_bias, float* row_stats, void* stream) {
+  if (row_stats != nullptr && (N % 16)) return VPR_ERR_UNSUPPORTED;
   if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return VPR_ERR_INVALID_ARG;
   if (mode != SK_ACCUMULATE && !bias) return VPR_ERR_INVALID_ARG;
   if (M == 0) return VPR_OK;
@@ -118,7 +146,7 @@ extern "C" int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_
   const bool bf = bias_is_bf16 || !bias;
 #define VPR_SKINNY_LAUNCH(T, NWV, MBV)                                                                              \
   VPR_TRY_LAUNCH(launch_kernel(skinny_linear_kernel<T, NWV, MBV>, grid, dim3(NWV * 64), 0, st, in, ldi, W, ldw,     \
-                               static_cast<const T*>(bias), mode, out, ldo, M, N, K))
+                               static_cast<const T*>(bias), mode, out, ldo, M, N, K, stats_bias, row_stats))
 #define VPR_SKINNY_NW(T, MBV)                                                                                       \
   do {                                                                                                              \
     if (nw == 16) VPR_SKINNY_LAUNCH(T, 16, MBV); else if (nw == 8) VPR_SKINNY_LAUNCH(T, 8, MBV); else VPR_SKINNY_LAUNCH(T, 4, MBV); \
@@ -128,4 +156,17 @@ extern "C" int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_
 #undef VPR_SKINNY_NW
 #undef VPR_SKINNY_LAUNCH
   return VPR_OK;
+}
+
+extern "C" int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+                                      int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
+                                      void* stream) {
+  return skinny_launch(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, nullptr, nullptr, stream);
+}
+
+extern "C" int vpr_skinny_linear_stats_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+                                            int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
+                                            const float* stats_bias, float* row_stats, void* stream) {
+  if (!row_stats) return VPR_ERR_INVALID_ARG;
+  return skinny_launch(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, stats_bias, row_stats, stream);
 }

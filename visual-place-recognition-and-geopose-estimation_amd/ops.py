@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import NamedTuple, Optional, Tuple
 
 import torch
 
@@ -434,9 +434,11 @@ def attention_qkv_split_bf16(qkv: torch.Tensor, B: int, T: int, body_tokens: int
 
 
 def skinny_linear_bf16(inp: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
-                       mode: int = 0) -> torch.Tensor:
+                       mode: int = 0, stats_bias: Optional[torch.Tensor] = None,
+                       row_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Linear layer on a few rows, written into `out` (a row slice of a larger buffer is fine):
-    mode 0 out = inp W^T + b; 1 gelu_tanh(inp W^T + b); 2 out += inp W^T."""
+    mode 0 out = inp W^T + b; 1 gelu_tanh(inp W^T + b); 2 out += inp W^T.  With row_stats [N/16, M, 2] f32 it
+    also leaves the per-16-column (mean, M2) of bf16(out) + stats_bias there (LayerNorm statistics partials)."""
     for t, name in ((inp, "inp"), (weight, "weight"), (out, "out")):
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
             raise RuntimeError(f"skinny_linear_bf16: {name} must be a GPU bf16 matrix with unit column stride")
@@ -448,8 +450,74 @@ def skinny_linear_bf16(inp: torch.Tensor, weight: torch.Tensor, bias: Optional[t
         if bias is None or not bias.is_cuda or bias.numel() != N or bias.dtype not in (torch.bfloat16, torch.float32) \
                 or not bias.is_contiguous():
             raise RuntimeError("skinny_linear_bf16: bias [N] bf16/f32 required")
+    if row_stats is not None:
+        _need(row_stats, torch.float32, "row_stats", 3)
+        if tuple(row_stats.shape) != (N // 16, M, 2) or N % 16:
+            raise RuntimeError("skinny_linear_bf16: row_stats must be [N/16, M, 2] with N % 16 == 0")
+        if stats_bias is not None:
+            _need(stats_bias, torch.float32, "stats_bias", 1)
+        st = _lib.lib().vpr_skinny_linear_stats_bf16(_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0),
+                                                     _ptr(bias) if mode != 2 else None,
+                                                     int(bias is not None and bias.dtype == torch.bfloat16), int(mode),
+                                                     _ptr(out), out.stride(0), M, N, K, _ptr(stats_bias), _ptr(row_stats),
+                                                     _stream())
+        _lib.check(st, "vpr_skinny_linear_stats_bf16")
+        return out
     st = _lib.lib().vpr_skinny_linear_bf16(_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias) if mode != 2 else None,
                                            int(bias is not None and bias.dtype == torch.bfloat16), int(mode),
                                            _ptr(out), out.stride(0), M, N, K, _stream())
     _lib.check(st, "vpr_skinny_linear_bf16")
     return out
+
+
+class ClsLinearConsts(NamedTuple):
+    """Static operands of the LayerNorm-fused cls-row linear (see vpr_bias_layernorm_cls_linear_bf16)."""
+    w_scaled: torch.Tensor     # [N, C] bf16 = W * gamma
+    colsum: torch.Tensor       # [N] f32
+    cprime: torch.Tensor       # [N] f32 = W' pre_bias
+    bprime: torch.Tensor       # [N] f32 = b + W beta
+
+    @staticmethod
+    def build(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+              pre_bias: Optional[torch.Tensor]) -> "ClsLinearConsts":
+        w32 = weight.detach().float()
+        ws = (w32 * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+        ws32 = ws.float()
+        cprime = ws32 @ pre_bias.float() if pre_bias is not None else torch.zeros(weight.shape[0], device=weight.device)
+        return ClsLinearConsts(ws, ws32.sum(1).contiguous(), cprime.contiguous(),
+                               (bias.detach().float() + w32 @ beta.detach().float()).contiguous())
+
+
+def bias_layernorm_cls_linear_bf16(x: torch.Tensor, pre_bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                                   beta: torch.Tensor, eps: float, cls_row0: int, row_stats: torch.Tensor,
+                                   consts: ClsLinearConsts, out: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+    """y = LayerNorm(x + pre_bias) for every row of x [M, C] (returned), and in the same launch
+    out[:] = act(y[cls_row0 : cls_row0 + out.shape[0]] W^T + b) (act = tanh-GELU if gelu), from the raw rows and
+    `consts` = ClsLinearConsts.build(W, b, gamma, beta, pre_bias).  row_stats: the statistics partials of those
+    rows, left by skinny_linear_bf16(..., row_stats=...) when it wrote them."""
+    _need(x, torch.bfloat16, "x", 2)
+    for t, name in ((gamma, "gamma"), (beta, "beta")):
+        _need(t, torch.bfloat16, name, 1)
+    if pre_bias is not None:
+        _need(pre_bias, torch.float32, "pre_bias", 1)
+    M, C = x.shape
+    n_cls, N = out.shape
+    _need(consts.w_scaled, torch.bfloat16, "w_scaled", 2)
+    for t, name in ((consts.colsum, "colsum"), (consts.cprime, "cprime"), (consts.bprime, "bprime")):
+        _need(t, torch.float32, name, 1)
+        if t.numel() != N:
+            raise RuntimeError("bias_layernorm_cls_linear_bf16: constant vector size")
+    if not out.is_cuda or out.dtype != torch.bfloat16 or out.stride(1) != 1:
+        raise RuntimeError("bias_layernorm_cls_linear_bf16: out must be a GPU bf16 matrix with unit column stride")
+    if consts.w_scaled.shape != (N, C) or gamma.numel() != C or beta.numel() != C:
+        raise RuntimeError("bias_layernorm_cls_linear_bf16: shape mismatch")
+    _need(row_stats, torch.float32, "row_stats", 3)
+    if tuple(row_stats.shape) != (C // 16, n_cls, 2):
+        raise RuntimeError("bias_layernorm_cls_linear_bf16: row_stats must be [C/16, n_cls, 2]")
+    y = torch.empty_like(x)
+    st = _lib.lib().vpr_bias_layernorm_cls_linear_bf16(_ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(beta), float(eps), _ptr(y),
+                                                       M, C, int(cls_row0), n_cls, _ptr(row_stats), _ptr(consts.w_scaled),
+                                                       consts.w_scaled.stride(0), _ptr(consts.colsum), _ptr(consts.cprime),
+                                                       _ptr(consts.bprime), int(gelu), _ptr(out), out.stride(0), N, _stream())
+    _lib.check(st, "vpr_bias_layernorm_cls_linear_bf16")
+    return y
