@@ -11,77 +11,90 @@ namespace vpr {
 // With `res` != nullptr the kernel first forms s = bf16(x + res) (the residual add PyTorch would do
 // as a separate pass), stores it to `sum_out`, and normalises s — one read of each operand, two
 // writes, instead of add (r2 w1) + LayerNorm (r1 w1).
-template <int NCH, typename ParamT>
+template <int NCH, typename ParamT, int RW>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ res, uint16_t* __restrict__ sum_out,
     const float* __restrict__ pre_bias, const ParamT* __restrict__ gamma, const ParamT* __restrict__ beta,
     float eps, uint16_t* __restrict__ y, long long M, int C) {
+  // RW rows per wave, all their 16-byte chunks requested before the first reduction (one round of
+  // workgroups for [16448, 1024] instead of two).  It did not pay: see launch_ln.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long row = (long long)blockIdx.x * 4 + wave;
-  if (row >= M) return;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * RW;
+  if (row0 >= M) return;
   const int nchunks = C >> 3;
-  const uint16_t* xr = x + row * C;
-  float v[NCH][8];
-  float s = 0.f;
+  float v[RW][NCH][8];
+  float s[RW];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nchunks) {
-      const s16x8 q = *reinterpret_cast<const s16x8*>(xr + ch * 8);
-      if (res != nullptr) {   // uniform
-        const s16x8 r = *reinterpret_cast<const s16x8*>(res + row * C + ch * 8);
+  for (int rr = 0; rr < RW; ++rr) {
+    const bool valid = row0 + rr < M;
+    const long long row = valid ? row0 + rr : M - 1;              // a clamped duplicate re-reads the last row, stores nothing
+    const uint16_t* xr = x + row * C;
+    s[rr] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nchunks) {
+        const s16x8 q = *reinterpret_cast<const s16x8*>(xr + ch * 8);
+        if (res != nullptr) {   // uniform
+          const s16x8 r = *reinterpret_cast<const s16x8*>(res + row * C + ch * 8);
+          s16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint16_t sb = f32_to_bf16_bits(bf16_bits_to_f32((uint16_t)q[e]) + bf16_bits_to_f32((uint16_t)r[e]));
+            o[e] = (short)sb;
+            v[rr][i][e] = bf16_bits_to_f32(sb);
+            s[rr] += v[rr][i][e];
+          }
+          if (valid) *reinterpret_cast<s16x8*>(sum_out + row * C + ch * 8) = o;
+        } else if (pre_bias != nullptr) {   // uniform: a per-column f32 offset carried outside the bf16 stream
+          const float4 p0 = *reinterpret_cast<const float4*>(pre_bias + ch * 8);
+          const float4 p1 = *reinterpret_cast<const float4*>(pre_bias + ch * 8 + 4);
+          const float pb[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[rr][i][e] = bf16_bits_to_f32((uint16_t)q[e]) + pb[e]; s[rr] += v[rr][i][e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[rr][i][e] = bf16_bits_to_f32((uint16_t)q[e]); s[rr] += v[rr][i][e]; }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[rr][i][e] = 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const long long row = row0 + rr;
+    if (row >= M) break;
+    const float mean = wave_sum(s[rr]) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (lane + 64 * i < nchunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[rr][i][e] - mean; ss = fmaf(d, d, ss); }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    uint16_t* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nchunks) {
         s16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const uint16_t sb = f32_to_bf16_bits(bf16_bits_to_f32((uint16_t)q[e]) + bf16_bits_to_f32((uint16_t)r[e]));
-          o[e] = (short)sb;
-          v[i][e] = bf16_bits_to_f32(sb);
-          s += v[i][e];
+          float g, b;
+          if constexpr (sizeof(ParamT) == 2) {
+            g = bf16_bits_to_f32((uint16_t)gamma[ch * 8 + e]);
+            b = bf16_bits_to_f32((uint16_t)beta[ch * 8 + e]);
+          } else {
+            g = gamma[ch * 8 + e];
+            b = beta[ch * 8 + e];
+          }
+          o[e] = (short)f32_to_bf16_bits((v[rr][i][e] - mean) * rstd * g + b);
         }
-        *reinterpret_cast<s16x8*>(sum_out + row * C + ch * 8) = o;
-      } else if (pre_bias != nullptr) {   // uniform: a per-column f32 offset carried outside the bf16 stream
-        const float4 p0 = *reinterpret_cast<const float4*>(pre_bias + ch * 8);
-        const float4 p1 = *reinterpret_cast<const float4*>(pre_bias + ch * 8 + 4);
-        const float pb[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[i][e] = bf16_bits_to_f32((uint16_t)q[e]) + pb[e]; s += v[i][e]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[i][e] = bf16_bits_to_f32((uint16_t)q[e]); s += v[i][e]; }
+        *reinterpret_cast<s16x8*>(yr + ch * 8) = o;
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    if (lane + 64 * i < nchunks) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; ss = fmaf(d, d, ss); }
-    }
-  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
-  uint16_t* yr = y + row * C;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nchunks) {
-      s16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float g, b;
-        if constexpr (sizeof(ParamT) == 2) {
-          g = bf16_bits_to_f32((uint16_t)gamma[ch * 8 + e]);
-          b = bf16_bits_to_f32((uint16_t)beta[ch * 8 + e]);
-        } else {
-          g = gamma[ch * 8 + e];
-          b = beta[ch * 8 + e];
-        }
-        o[e] = (short)f32_to_bf16_bits((v[i][e] - mean) * rstd * g + b);
-      }
-      *reinterpret_cast<s16x8*>(yr + ch * 8) = o;
     }
   }
 }
@@ -89,15 +102,24 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(
 template <typename ParamT>
 static int launch_ln(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const float* pb, const ParamT* g, const ParamT* b,
                      float eps, uint16_t* y, long long M, int C, hipStream_t stream) {
-  const dim3 grid((unsigned)((M + 3) / 4));
   const int nch = (C / 8 + 63) / 64;
+  const char* venv = getenv("VPR_LN_ROWS");              // A/B switch: rows per wave.  Measured in bench.py on one box:
+  const int rw = venv ? atoi(venv) : 1;                  // 2 rows 11.80/11.80 ms per step, 1 row 11.75/11.72 -> default 1
+#define VPR_LN_LAUNCH(NCHV, RWV)                                                                                   \
+  VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<NCHV, ParamT, RWV>, dim3((unsigned)((M + 4 * RWV - 1) / (4 * RWV))), \
+                               dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C))
+  if (rw == 2 && nch <= 2) {
+    if (nch == 1) VPR_LN_LAUNCH(1, 2); else VPR_LN_LAUNCH(2, 2);
+    return VPR_OK;
+  }
   switch (nch) {
-    case 1: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<1, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
-    case 2: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<2, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
-    case 3: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<3, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
-    case 4: VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<4, ParamT>, grid, dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C)); break;
+    case 1: VPR_LN_LAUNCH(1, 1); break;
+    case 2: VPR_LN_LAUNCH(2, 1); break;
+    case 3: VPR_LN_LAUNCH(3, 1); break;
+    case 4: VPR_LN_LAUNCH(4, 1); break;
     default: return VPR_ERR_UNSUPPORTED;
   }
+#undef VPR_LN_LAUNCH
   return VPR_OK;
 }
 
