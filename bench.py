@@ -182,16 +182,16 @@ def main():
         with open(pmc) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
 
-    if bq < 256:
+    if bq <= 64:
         roofline = {"bound": "hbm", "kernel": "knn_scores_kernel",
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}
     else:
-        # >= 256 gathered queries per shard scan: 2*bq FLOP per gallery byte is past the bf16 ridge
-        # (~310 FLOP/B), so vpr_knn_scores runs the score tile as an MFMA GEMM (gemm_nt_kernel)
+        # more than one 64-query tile per shard scan (multi-GPU: all-gathered queries): vpr_knn_scores runs the
+        # score tile as an MFMA GEMM (gemm_nt_kernel) — one gallery pass per 128 queries, 2*bq FLOP per gallery byte
         flops = 2.0 * bq * n_shard * D_DESC
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (score tile, query batch >= 256)",
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (score tile, query batch > 64)",
                     "achieved": flops / knn_avg_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / knn_avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_flops": flops}

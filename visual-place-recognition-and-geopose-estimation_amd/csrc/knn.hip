@@ -751,10 +751,13 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   if (st != VPR_OK) return st;
   if (ws_bytes < p.total) return VPR_ERR_WORKSPACE;
   float* S = reinterpret_cast<float*>(static_cast<char*>(ws) + p.off_S);
-  // Many queries against a short shard (the all-gathered batch of an 8-GPU job: 512 x 12.5k) is a
-  // compute-bound GEMM, not a stream: the 128x128-tile MFMA GEMM reads the shard once per 128
-  // queries instead of once per 64 (3.4x faster at that shape).
-  if (!o.fp8 && B >= 256)
+  // More than one 64-query tile against a shard (the all-gathered batch of a multi-GPU job) moves
+  // towards a compute-bound GEMM: the streaming kernel makes one gallery pass per 64 queries, the
+  // 128x128-tile MFMA GEMM one per 128.  Measured, stream vs GEMM: 128 x 50k 367 / 222 us,
+  // 192 x 33k 406 / 300, 256 x 25k 477 / 185, 512 x 12.5k 702 / 151 (scripts/knn_b_sweep.py).
+  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the crossover
+  const int gemm_min_b = genv ? atoi(genv) : 65;
+  if (!o.fp8 && B >= gemm_min_b)
     return launch_gemm_nt(static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr,
                           0, S, p.ldS, 0, B, N, D, stream);
   // Tile height / residency variants (same arithmetic, same results); 0 is the default, the
