@@ -85,8 +85,10 @@ def main():
         flops = B * (2 * 256 * C * 1024 + 2 * 256 * 512 * 192 + 2 * C * 512 + 2 * 512 * 256 + 2 * 128 * 64 * 256)
         res["salad_total"] = dict(ms=med * 1e3, best_ms=best * 1e3, TFLOPs=flops / med / 1e12)
         x = tokens[:, 1:, :].reshape(B * 256, C).contiguous()
+        med, best = timeit(lambda: ops.gemm_nt_bf16(x, w.w1_sc, w.b1_sc, True, torch.bfloat16, tile256=True), a.iters)
+        res["salad_gemm_l1"] = dict(ms=med * 1e3, TFLOPs=2 * B * 256 * C * 1024 / med / 1e12, kernel="gemm256_kernel")
         med, best = timeit(lambda: ops.gemm_nt_bf16(x, w.w1_sc, w.b1_sc, True, torch.bfloat16), a.iters)
-        res["salad_gemm_l1"] = dict(ms=med * 1e3, TFLOPs=2 * B * 256 * C * 1024 / med / 1e12)
+        res["salad_gemm_l1_tile128"] = dict(ms=med * 1e3, TFLOPs=2 * B * 256 * C * 1024 / med / 1e12)
         sc = torch.randn(B, 256, 64, device=dev, generator=g)
         ft = torch.randn(B, 256, 128, device=dev, generator=g)
         tk = torch.randn(B, 256, device=dev, generator=g)

@@ -280,13 +280,18 @@ static int salad_run(const uint16_t* patch, long long patch_img_stride, const ui
   uint16_t* Ht = reinterpret_cast<uint16_t*>(ws + p.off_Ht);
   float* g = reinterpret_cast<float*>(ws + p.off_g);
   int st;
-  // Launch 1: fused score+cluster layer 1 on the patch tokens (row r of image b at
-  // tokens + b*img_stride + (1 + r)*C) together with token-MLP layer 1 on the cls tokens
-  // (image b at tokens + b*img_stride).
-  const GemmProblem l1[2] = {
-      {patch, C, n, patch_img_stride, w->w1_sc, C, w->b1_sc, 1, H, 2 * hidden, 1, B * n, 2 * hidden, C, 0, 0},
-      {cls, (int)cls_stride, 0, 0, w->w1_t, C, w->b1_t, 1, Ht, hidden, 1, B, hidden, C, 0, 0}};
-  st = launch_gemm_nt_group(l1, 2, stream);
+  // Layer 1.  The fused score+cluster GEMM on the patch tokens (row r of image b at patch + b*stride + r*C,
+  // addressed in place) is 34 of SALAD's 38 GFLOP: it runs on the 256x256-tile kernel (B tiles x 4 = one
+  // full wave of workgroups at B = 64; 39.5 us vs 57 us on the 128x128 tile).  Token-MLP layer 1 (B rows)
+  // would be two extra workgroups, i.e. a second wave, so it goes through the skinny-rows kernel first.
+  const GemmProblem l1_sc{patch, C, n, patch_img_stride, w->w1_sc, C, w->b1_sc, 1, H, 2 * hidden, 1, B * n, 2 * hidden, C, 0, 0};
+  st = launch_skinny_linear(cls, (int)cls_stride, w->w1_t, C, w->b1_t, 0, 3, Ht, hidden, B, hidden, C, nullptr, nullptr, stream);
+  if (st == VPR_OK) st = launch_gemm256(l1_sc, stream);
+  if (st == VPR_ERR_UNSUPPORTED) {   // shapes outside the two kernels' domains: both on the grouped 128-tile launch
+    const GemmProblem l1[2] = {
+        l1_sc, {cls, (int)cls_stride, 0, 0, w->w1_t, C, w->b1_t, 1, Ht, hidden, 1, B, hidden, C, 0, 0}};
+    st = launch_gemm_nt_group(l1, 2, stream);
+  }
   if (st != VPR_OK) return st;
   // Launch 2: the three second layers (scores, cluster features, token features).
   const GemmProblem l2[3] = {

@@ -13,7 +13,7 @@
 
 namespace vpr {
 
-enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2 };
+enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2, SK_BIAS_RELU = 3 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2 u): the form hipBLASLt's epilogue uses
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
         if constexpr (sizeof(BiasT) == 2) b = bf16_bits_to_f32((uint16_t)bias[n + e]); else b = bias[n + e];
         v[e] += b;
         if (mode == SK_BIAS_GELU) v[e] = gelu_tanh(v[e]);
+        if (mode == SK_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
       }
       ob[e] = f32_to_bf16_bits(v[e]);
     }
@@ -124,13 +125,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
 
 }  // namespace vpr
 
-using namespace vpr;
-
-static int skinny_launch(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
+namespace vpr {
+int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
                          int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
                          const float* stats_bias, float* row_stats, void* stream) {
   if (row_stats != nullptr && (N % 16)) return VPR_ERR_UNSUPPORTED;
-  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return VPR_ERR_INVALID_ARG;
+  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 3) return VPR_ERR_INVALID_ARG;
   if (mode != SK_ACCUMULATE && !bias) return VPR_ERR_INVALID_ARG;
   if (M == 0) return VPR_OK;
   if ((K % 32) || (ldi % 8) || (ldw % 8) || ldi < K || ldw < K || ldo < N) return VPR_ERR_UNSUPPORTED;
@@ -157,16 +157,19 @@ static int skinny_launch(const uint16_t* in, int ldi, const uint16_t* W, int ldw
 #undef VPR_SKINNY_LAUNCH
   return VPR_OK;
 }
+}  // namespace vpr
+
+using namespace vpr;
 
 extern "C" int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
                                       int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
                                       void* stream) {
-  return skinny_launch(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, nullptr, nullptr, stream);
+  return launch_skinny_linear(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, nullptr, nullptr, stream);
 }
 
 extern "C" int vpr_skinny_linear_stats_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
                                             int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
                                             const float* stats_bias, float* row_stats, void* stream) {
   if (!row_stats) return VPR_ERR_INVALID_ARG;
-  return skinny_launch(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, stats_bias, row_stats, stream);
+  return launch_skinny_linear(in, ldi, W, ldw, bias, bias_is_bf16, mode, out, ldo, M, N, K, stats_bias, row_stats, stream);
 }

@@ -22,6 +22,10 @@ struct GemmProblem {
 constexpr int GEMM_MAX_GROUP = 3;
 int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
 int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
+// skinny.hip: a few rows x [N, K]^T; mode 0 bias, 1 bias+tanh-GELU, 2 accumulate into out, 3 bias+ReLU
+int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias, int bias_is_bf16,
+                         int mode, uint16_t* out, int ldo, int M, int N, int K, const float* stats_bias,
+                         float* row_stats, void* stream);
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
