@@ -177,6 +177,18 @@ int vpr_pose_head(const float* x, const float* W1, const float* b1,
                   int B, int D, int hidden, int n_out, int sincos_offset,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same MLP head with the first layer on the bf16 matrix pipe at f32 accuracy: W1 packed once by
+ * vpr_pose_head_pack_w1 into two bf16 planes (hi = bf16(w), lo = bf16(w - hi): the same 4 bytes per weight),
+ * x split the same way on the fly, (x_hi + x_lo)(w_hi + w_lo) = four exact-product MFMAs with f32 accumulation
+ * (<= 2^-16 relative per product; the f32 MFMA of vpr_pose_head runs at 1/16 of the bf16 rate and costs as
+ * much time as the weight stream).  Split-K slabs summed in a fixed order: bitwise reproducible.
+ * Requires D % 32 == 0, hidden % 16 == 0, hidden > 0, 1 <= n_out <= 8; W1_hi / W1_lo [hidden, D]. */
+int vpr_pose_head_pack_w1(const float* W1, long long count, uint16_t* hi, uint16_t* lo, void* stream);
+size_t vpr_pose_head_split_workspace_bytes(int B, int D, int hidden);
+int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const uint16_t* W1_lo, const float* b1,
+                        const float* W2, const float* b2, float* out, int B, int D, int hidden,
+                        int n_out, int sincos_offset, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh
  * Replaces: `outputs.pooler_output` + `self.regressor`  swin_transformer/swin_validation.py:43-46

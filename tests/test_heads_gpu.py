@@ -21,17 +21,21 @@ def _linear_init(out_f, in_f, g):
     (7, 768, 384, 2, 0),        # sin/cos MLP head, ragged batch
     (1, 64, 32, 1, -1),
 ])
-def test_mlp_head(dev, B, D, hidden, n_out, off):
+@pytest.mark.parametrize("split", [True, False])
+def test_mlp_head(dev, B, D, hidden, n_out, off, split):
+    """split=True: first layer as four bf16 MFMAs on (hi, lo) planes (default); False: exact-f32 MFMA.  Both must
+    sit far inside the 1e-4 tolerance: the split path's error budget is 2^-16 per product, ~1e-7 on the output."""
     from vpr_amd import ops
     g = torch.Generator().manual_seed(B + D)
     x = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1) if D == 8448 else torch.randn(B, D, generator=g)
     W1, b1 = _linear_init(hidden, D, g)
     W2, b2 = _linear_init(n_out, hidden, g)
     ref = oheads.mlp_head(x, W1, b1, W2, b2, off)
-    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), off).cpu().double()
+    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), off, split=split).cpu().double()
     err = (out - ref).abs().max().item()
     print("mlp head err", err)
     assert err < TOL
+    assert err < 2e-5 * max(1.0, ref.abs().max().item())          # f32-level, both paths (O(1) randn inputs: ~1e-5)
 
 
 @pytest.mark.parametrize("B,D,n_out,off", [(8, 768, 2, -1), (8, 768, 2, 0), (33, 1024, 4, 2)])

@@ -249,6 +249,105 @@ __global__ __launch_bounds__(256) void ln_meanpool_head_kernel(
   finish_outputs(outs, n_out, sincos_offset, out + (long long)b * n_out);
 }
 
+// ---- first layer on the bf16 matrix pipe at f32 accuracy -------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate: at B = 64, hidden = 1024 the 1.1 GFLOP of the first
+// layer are 7 us of matrix-pipe time on their own, as much as the 34.6 MB weight stream.  Every f32 value
+// is the sum of two bf16 values to 2^-17 (hi = bf16(v), lo = bf16(v - hi)), products of bf16 pairs are exact
+// in f32, so  x w = (x_hi + x_lo)(w_hi + w_lo)  is four bf16 MFMAs with f32 accumulation: error per product
+// <= 2^-16 relative (random sign), i.e. ~1e-7 absolute on outputs of magnitude 0.1 — the size of the f32
+// summation error itself.  W1 is packed once into (hi, lo) bf16 planes: the same 4 bytes per weight.
+__global__ __launch_bounds__(256) void pose_pack_split_kernel(const float* __restrict__ w, long long count,
+                                                              uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float v = w[i];
+  const uint16_t h = f32_to_bf16_bits(v);
+  hi[i] = h;
+  lo[i] = f32_to_bf16_bits(v - bf16_bits_to_f32(h));
+}
+
+__device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {       // hardware RNE conversions (v_cvt_pk_bf16_f32): 3 VALU ops per element
+    hi[e] = (__bf16)v[e];
+    lo[e] = (__bf16)(v[e] - (float)hi[e]);
+  }
+}
+
+// grid (hidden / 64, nslice, ceil(B / 64)); workgroup = 64 hidden units x 64 batch rows x one K slice; wave w owns
+// hidden units 16w .. 16w+15 (its own accumulators, no cross-wave reduction), the four waves read the same x
+// fragments (L1 hits), so x crosses the L2 once per 64 hidden units (16 per workgroup cost 138 MB of L2 reads).
+__global__ __launch_bounds__(256) void pose_l1_split_kernel(
+    const float* __restrict__ x, const uint16_t* __restrict__ Whi, const uint16_t* __restrict__ Wlo,
+    float* __restrict__ part, int B, int D, int hidden, int steps_per_slice) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16, ks = blockIdx.y, m0 = blockIdx.z * 64;
+  const int ksteps = D >> 5;
+  const int kbeg = ks * steps_per_slice, kend = min(ksteps, kbeg + steps_per_slice);
+  const long long wrow = (long long)min(n0 + r, hidden - 1) * D + 8 * g;
+  const float* xp[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) xp[mb] = x + (long long)min(m0 + mb * 16 + r, B - 1) * D + 8 * g;
+  f32x4 acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mac = [&](const bf16x8& wh, const bf16x8& wl, const float4& xa, const float4& xb, f32x4& c) {
+    bf16x8 xh, xl;
+    split8(xa, xb, xh, xl);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl, c, 0, 0, 0);     // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+  };
+  int s = kbeg;
+  for (; s + 2 <= kend; s += 2) {               // two K-steps per round trip: 20 x 16-byte loads in flight per lane
+    bf16x8 wh[2], wl[2];
+    float4 xa[2][4], xb[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      wh[u] = *reinterpret_cast<const bf16x8*>(Whi + wrow + (s + u) * 32);
+      wl[u] = *reinterpret_cast<const bf16x8*>(Wlo + wrow + (s + u) * 32);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        xa[u][mb] = *reinterpret_cast<const float4*>(xp[mb] + (s + u) * 32);
+        xb[u][mb] = *reinterpret_cast<const float4*>(xp[mb] + (s + u) * 32 + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) mac(wh[u], wl[u], xa[u][mb], xb[u][mb], acc[mb]);
+  }
+  for (; s < kend; ++s) {
+    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(Whi + wrow + s * 32);
+    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(Wlo + wrow + s * 32);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+      mac(wh, wl, *reinterpret_cast<const float4*>(xp[mb] + s * 32), *reinterpret_cast<const float4*>(xp[mb] + s * 32 + 4), acc[mb]);
+  }
+  // C/D: col = batch row (lane & 15) of block mb, rows 4g+e = 4 consecutive hidden units
+  if (n0 + 4 * g < hidden) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + mb * 16 + r;
+      if (m < B) *reinterpret_cast<f32x4*>(part + ((long long)ks * B + m) * hidden + n0 + 4 * g) = acc[mb];
+    }
+  }
+}
+
+static int pick_slices_split(int B, int D, int hidden) {
+  // ~512-768 workgroups; a slice at least 4 K-steps (two round trips)
+  const int tiles = ((hidden + 63) / 64) * ((B + 63) / 64);
+  int ks = (640 + tiles - 1) / tiles;
+  const int max_ks = (D / 32) / 4 > 0 ? (D / 32) / 4 : 1;
+  if (ks > max_ks) ks = max_ks;
+  if (ks > 32) ks = 32;
+  if (ks < 1) ks = 1;
+  return ks;
+}
+
 static int pick_slices(int B, int D, int hidden) {
   // aim at ~512 workgroups; each slice at least 8 MFMA k-steps (128 of D)
   const int tiles = (hidden / PH_HT) * ((B + PH_BT - 1) / PH_BT);
@@ -326,5 +425,43 @@ extern "C" int vpr_ln_meanpool_head(const void* x, int x_is_bf16, int B, int T, 
     case 1536: return launch_ln<24>(x, x_is_bf16, B, T, gamma, beta, eps, pooled_out, Wh, bh, n_out, sincos_offset, out, stream);
     default: return VPR_ERR_UNSUPPORTED;
   }
+  return VPR_OK;
+}
+
+/* W1 f32 [count] -> (hi, lo) bf16 planes with hi + lo == W1 to 2^-17 relative. */
+extern "C" int vpr_pose_head_pack_w1(const float* W1, long long count, uint16_t* hi, uint16_t* lo, void* stream) {
+  if (!W1 || !hi || !lo || count < 0) return VPR_ERR_INVALID_ARG;
+  if (count == 0) return VPR_OK;
+  if ((count + 255) / 256 > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
+  VPR_TRY_LAUNCH(launch_kernel(pose_pack_split_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), W1, count, hi, lo));
+  return VPR_OK;
+}
+
+extern "C" size_t vpr_pose_head_split_workspace_bytes(int B, int D, int hidden) {
+  if (B <= 0 || D <= 0 || hidden <= 0) return 0;
+  return align_up((size_t)pick_slices_split(B, D, hidden) * B * hidden * sizeof(float), 256);
+}
+
+extern "C" int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const uint16_t* W1_lo, const float* b1,
+                                   const float* W2, const float* b2, float* out, int B, int D, int hidden,
+                                   int n_out, int sincos_offset, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (!x || !W1_hi || !W1_lo || !b1 || !W2 || !b2 || !out || !workspace || B <= 0 || D <= 0 || hidden <= 0 || n_out < 1)
+    return VPR_ERR_INVALID_ARG;
+  if (n_out > 8 || (D % 32) || (hidden % 16)) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W1_hi) | reinterpret_cast<uintptr_t>(W1_lo) |
+       reinterpret_cast<uintptr_t>(workspace)) & 15)
+    return VPR_ERR_UNSUPPORTED;
+  const int ks = pick_slices_split(B, D, hidden);
+  if (workspace_bytes < (size_t)ks * B * hidden * sizeof(float)) return VPR_ERR_WORKSPACE;
+  const int ksteps = D / 32;
+  const int sps = (ksteps + ks - 1) / ks;
+  float* part = static_cast<float*>(workspace);
+  VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), 0, stream, x,
+                               W1_hi, W1_lo, part, B, D, hidden, sps));
+  VPR_TRY_LAUNCH(launch_kernel(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
+                               hidden, n_out, sincos_offset));
   return VPR_OK;
 }

@@ -273,9 +273,29 @@ def topk_merge(vals: torch.Tensor, idxs: torch.Tensor) -> Tuple[torch.Tensor, to
 
 
 # ------------------------------------------------------------------------------------------ heads
+_POSE_PLANES: dict = {}
+
+
+def _pose_w1_planes(W1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(hi, lo) bf16 planes of a first-layer weight, packed once per (storage, version) by vpr_pose_head_pack_w1."""
+    key = (W1.data_ptr(), W1._version, tuple(W1.shape), str(W1.device))
+    hit = _POSE_PLANES.get(key)
+    if hit is None:
+        if len(_POSE_PLANES) > 16:
+            _POSE_PLANES.clear()
+        hi = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
+        lo = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
+        st = _lib.lib().vpr_pose_head_pack_w1(_ptr(W1), W1.numel(), _ptr(hi), _ptr(lo), _stream())
+        _lib.check(st, "vpr_pose_head_pack_w1")
+        hit = _POSE_PLANES[key] = (hi, lo)
+    return hit
+
+
 def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Tensor], W2: torch.Tensor,
-              b2: torch.Tensor, sincos_offset: int = -1) -> torch.Tensor:
-    """W2 relu(W1 x + b1) + b2 in f32 (W1 None -> single Linear); optional unit-normalised pair."""
+              b2: torch.Tensor, sincos_offset: int = -1, split: bool = True) -> torch.Tensor:
+    """W2 relu(W1 x + b1) + b2 in f32 (W1 None -> single Linear); optional unit-normalised pair.
+    split: first layer as four bf16 MFMAs on (hi, lo) planes of x and W1 (f32 accuracy, ~3x faster than the
+    exact-f32 MFMA path, which split=False keeps)."""
     _need(x, torch.float32, "x", 2)
     _need(W2, torch.float32, "W2", 2)
     _need(b2, torch.float32, "b2", 1)
@@ -293,8 +313,15 @@ def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Te
     if b2.numel() != n_out:
         raise RuntimeError("pose_head: b2 size")
     L = _lib.lib()
-    ws = workspace("pose", L.vpr_pose_head_workspace_bytes(B, D, hidden, n_out), x.device)
     out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    if hidden > 0 and split and D % 32 == 0 and hidden % 16 == 0:
+        hi, lo = _pose_w1_planes(W1)
+        ws = workspace("pose", L.vpr_pose_head_split_workspace_bytes(B, D, hidden), x.device)
+        st = L.vpr_pose_head_split(_ptr(x), _ptr(hi), _ptr(lo), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), B, D, hidden,
+                                   n_out, int(sincos_offset), _ptr(ws), ws.numel(), _stream())
+        _lib.check(st, "vpr_pose_head_split")
+        return out
+    ws = workspace("pose", L.vpr_pose_head_workspace_bytes(B, D, hidden, n_out), x.device)
     st = L.vpr_pose_head(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), B, D, hidden, n_out,
                          int(sincos_offset), _ptr(ws), ws.numel(), _stream())
     _lib.check(st, "vpr_pose_head")
