@@ -153,7 +153,7 @@ def main():
 
     from vpr_amd.backbone import gemm_autotune
     if not a.no_tune:
-        gemm_autotune(True, tuning=True)        # picks the backbone GEMM kernels during warm-up
+        gemm_autotune(True, tuning=True, max_ms_per_gemm=int(os.environ.get("VPR_TUNE_MS", "30")))   # picks the backbone GEMM kernels during warm-up
     for _ in range(max(a.warmup, 1)):
         pipe.step(images)
     if not a.no_tune:

@@ -267,6 +267,7 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
   switch (variant) {
     case 1: VPR_ATTN_LAUNCH(4, false); break;
     case 2: VPR_ATTN_LAUNCH(4, true); break;
+    case 3: VPR_ATTN_LAUNCH(6, false); break;
     default: VPR_ATTN_LAUNCH(8, false); break;
   }
 #undef VPR_ATTN_LAUNCH
