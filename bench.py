@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-resid-gemm", action="store_true", help="residual add fused into the LayerNorm instead of the proj/fc2 GEMM (A/B)")
     ap.add_argument("--no-split", action="store_true", help="backbone in the cls-first [B,257,C] row layout (M = 64.25 tile rows) instead of patch rows | cls rows (A/B)")
     ap.add_argument("--fuse-ln-cls", action="store_true", help="cls-row qkv/fc1 ride in the LayerNorm launch instead of separate 64-row launches (A/B)")
+    ap.add_argument("--cls-before-gemm", action="store_true", help="cls-row launches before the library GEMM that shares their weights (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -131,6 +132,7 @@ def main():
     ext.backbone.residual_in_gemm = not a.no_resid_gemm
     ext.backbone.hip_split = not a.no_split
     ext.backbone.fuse_ln_cls = a.fuse_ln_cls
+    ext.backbone.cls_after_gemm = not a.cls_before_gemm
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))

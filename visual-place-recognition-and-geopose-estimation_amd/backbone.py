@@ -131,6 +131,7 @@ class DinoV2(nn.Module):
         return SplitTokens(x[:, 1:].contiguous(), x[:, 0].contiguous()) if split else x
 
     hip_split = True
+    cls_after_gemm = True
     fuse_ln_cls = False     # measured: 11.17/11.23 vs 11.22/11.26 ms per step — within noise, so the simpler path is the default
 
     def _hip_split_ok(self, img: torch.Tensor) -> bool:
@@ -193,24 +194,36 @@ class DinoV2(nn.Module):
         x, h = ops.add_layernorm_bf16(raw, off, n0.weight, n0.bias, n0.eps)
         cum = self._cumulative_bias(dev)
 
-        # patch rows: library GEMMs; cls rows: vpr_skinny_linear_bf16 (a library GEMM spends 9-14 us on 64
-        # rows).  (Tried: proj over all B*n + B rows in one GEMM: 50 us vs 38 + 8; the cls-row kernels on a side stream, forked after each LayerNorm and joined before
-        # the next consumer — the cross-queue waits cost more than the ~5 us launches they hide:
-        # 12.8 vs 12.2 ms/step.)
-        # fuse_ln_cls: the two cls-row linears that directly follow a LayerNorm (qkv, fc1) ride in the
-        # LayerNorm's launch (vpr_bias_layernorm_cls_linear_bf16).  The launch gets ~5 us longer, the
-        # separate 64-row launch was ~7.5 us: 0.03-0.05 ms per step, kept as an option only.
+        # patch rows: library GEMMs; cls rows: vpr_skinny_linear_bf16 (a library GEMM spends 9-14 us on 64 rows).
+        # cls_after_gemm: each cls-row launch comes right AFTER the library GEMM that used the same weight
+        # matrix (the 2-8 MB it streams could then be cache-resident).  Measured equal to "before":
+        # 11.20 / 11.16 vs 11.12 / 11.17 ms per step — the launches are latency-, not bandwidth-bound.
+        # Tried and dropped: proj over all B*n + B rows in one GEMM (50 us vs 38 + 8); the cls-row kernels on
+        # a side stream (cross-queue waits: 12.8 vs 12.2 ms/step).
+        # fuse_ln_cls (option): the two cls-row linears that directly follow a LayerNorm (qkv, fc1) ride in
+        # the LayerNorm's launch (vpr_bias_layernorm_cls_linear_bf16): 0.03-0.05 ms per step, default off.
         fuse = self.fuse_ln_cls and C % 32 == 0
+        after = self.cls_after_gemm
         rs = torch.empty((C // 16, B, 2), dtype=torch.float32, device=dev) if fuse else None   # stream-ordered reuse
         fc = self._cls_fused_consts(dev) if fuse else None
         C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
+
+        def pair(big, small, do_small=True):     # the library GEMM on the patch rows and the cls-row launch, in either order
+            if do_small and not after:
+                small()
+            big()
+            if do_small and after:
+                small()
+
         qkv = torch.empty((M, C3), dtype=bf, device=dev)
-        ops.skinny_linear_bf16(h[Mp:], blocks[0].qkv.weight, blocks[0].qkv.bias, qkv[Mp:], 0)
+        cls_qkv_pending = True                   # False once a fused LayerNorm launch has produced qkv[Mp:]
         for i, blk in enumerate(blocks):
-            torch.addmm(blk.qkv.bias, h[:Mp], blk.qkv.weight.t(), out=qkv[:Mp])
+            last = i + 1 == len(blocks)
+            pair(lambda: torch.addmm(blk.qkv.bias, h[:Mp], blk.qkv.weight.t(), out=qkv[:Mp]),
+                 lambda: ops.skinny_linear_bf16(h[Mp:], blk.qkv.weight, blk.qkv.bias, qkv[Mp:], 0), cls_qkv_pending)
             att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
-            ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, x[Mp:], 2, cum[2 * i] if fuse else None, rs)
-            x[:Mp].addmm_(att[:Mp], blk.proj.weight.t())
+            pair(lambda: x[:Mp].addmm_(att[:Mp], blk.proj.weight.t()),
+                 lambda: ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, x[Mp:], 2, cum[2 * i] if fuse else None, rs))
             hh = torch.empty((M, C4), dtype=bf, device=dev)
             n2 = blk.norm2
             if fuse:
@@ -218,13 +231,12 @@ class DinoV2(nn.Module):
                                                        fc[2 * i + 1], hh[Mp:], gelu=True)
             else:
                 h = ops.bias_layernorm_bf16(x, cum[2 * i], n2.weight, n2.bias, n2.eps)
-                ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1)
-            torch._addmm_activation(blk.fc1.bias, h[:Mp], blk.fc1.weight.t(), use_gelu=True, out=hh[:Mp])
-            last = i + 1 == len(blocks)
-            ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2,
-                                   cum[2 * i + 1] if fuse and not last else None, rs if not last else None)
-            x[:Mp].addmm_(hh[:Mp], blk.fc2.weight.t())
-            if i + 1 < len(blocks):
+            pair(lambda: torch._addmm_activation(blk.fc1.bias, h[:Mp], blk.fc1.weight.t(), use_gelu=True, out=hh[:Mp]),
+                 lambda: ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1), not fuse)
+            pair(lambda: x[:Mp].addmm_(hh[:Mp], blk.fc2.weight.t()),
+                 lambda: ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2,
+                                                cum[2 * i + 1] if fuse and not last else None, rs if not last else None))
+            if not last:
                 nb = blocks[i + 1]
                 qkv = torch.empty((M, C3), dtype=bf, device=dev)
                 if fuse:
@@ -232,7 +244,7 @@ class DinoV2(nn.Module):
                                                            Mp, rs, fc[2 * i + 2], qkv[Mp:])
                 else:
                     h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], nb.norm1.weight, nb.norm1.bias, nb.norm1.eps)
-                    ops.skinny_linear_bf16(h[Mp:], nb.qkv.weight, nb.qkv.bias, qkv[Mp:], 0)
+                cls_qkv_pending = not fuse
             else:
                 h = ops.bias_layernorm_bf16(x, cum[2 * i + 1], self.norm.weight, self.norm.bias, self.norm.eps)
         return SplitTokens(h[:Mp].view(B, n, C), h[Mp:])
