@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="backbone in the cls-first [B,257,C] row layout (M = 64.25 tile rows) instead of patch rows | cls rows (A/B)")
     ap.add_argument("--fuse-ln-cls", action="store_true", help="cls-row qkv/fc1 ride in the LayerNorm launch instead of separate 64-row launches (A/B)")
     ap.add_argument("--cls-before-gemm", action="store_true", help="cls-row launches before the library GEMM that shares their weights (A/B)")
+    ap.add_argument("--knn-dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="gallery / query storage for the kNN stage: bf16 (headline) or e4m3 + per-row scale (BASELINE config 5 flavour)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -142,7 +144,15 @@ def main():
 
     lo, hi = shard_bounds(a.gallery, rank, world)
     shard = make_gallery_shard(hi - lo, 1 + rank, dev)
-    gallery = ShardedGallery(shard, a.gallery, rank, world)
+    if a.knn_dtype == "fp8":
+        g8 = torch.empty((hi - lo, D_DESC), dtype=torch.uint8, device=dev)
+        gs = torch.empty((hi - lo,), dtype=torch.float32, device=dev)
+        for r0 in range(0, hi - lo, 65536):                                     # slabs: the f32 copy of a big shard is 4x its bf16 size
+            q8, qs = ops.quantize_fp8_rows(shard[r0:r0 + 65536].float())
+            g8[r0:r0 + 65536], gs[r0:r0 + 65536] = q8, qs
+        gallery = ShardedGallery(g8, a.gallery, rank, world, scales=gs)
+    else:
+        gallery = ShardedGallery(shard, a.gallery, rank, world)
     pipe = VPRGeoPosePipeline(ext, head, gallery, a.k)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
@@ -177,15 +187,16 @@ def main():
     knn_avg_s = sum(knn_ms) / len(knn_ms) * 1e-3
     pipe.knn_events = None
     n_shard, bq = hi - lo, a.batch * world
-    alg_bytes = n_shard * D_DESC * 2 + bq * D_DESC * 2 + bq * a.k * 8      # SURVEY §8d per query batch
+    esz = 1 if a.knn_dtype == "fp8" else 2
+    alg_bytes = n_shard * D_DESC * esz + bq * D_DESC * esz + bq * a.k * 8   # SURVEY §8d per query batch (s = 2 bf16, 1 fp8)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc.json")
-    if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64:
+    if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64 and a.knn_dtype == "bf16":
         with open(pmc) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
 
-    if bq <= 64:
-        roofline = {"bound": "hbm", "kernel": "knn_scores_kernel",
+    if bq <= 64 or a.knn_dtype == "fp8":
+        roofline = {"bound": "hbm", "kernel": "knn_scores_kernel" if a.knn_dtype == "bf16" else "vpr_knn_topk_fp8 (quantise queries + knn_scores_kernel<fp8> + select)",
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}
@@ -203,7 +214,10 @@ def main():
         gp = torch.Generator(device=dev).manual_seed(7)
         pos_idx = torch.randint(0, n_shard, (a.batch,), device=dev, generator=gp)
         qn = torch.nn.functional.normalize(shard[pos_idx].float() + 0.1 * torch.randn(a.batch, D_DESC, device=dev, generator=gp), dim=1)
-        _, ti = ops.knn_topk(qn.to(torch.bfloat16), shard, 1, lo)
+        if a.knn_dtype == "fp8":
+            _, ti = gallery.engine.local_topk(qn.to(torch.bfloat16), gallery.rows, 1, lo, gallery.scales)
+        else:
+            _, ti = ops.knn_topk(qn.to(torch.bfloat16), shard, 1, lo)
         recall1 = float((ti[:, 0].long() == pos_idx + lo).double().mean())
 
         # per-stage device time (one extra step each, outside the timed region)
@@ -219,7 +233,7 @@ def main():
         stages["backbone_ms"], tokens = stage_ms(lambda: ext.backbone(images, split=True))
         stages["salad_ms"], (desc, desc16) = stage_ms(lambda: ext.aggregator(tokens, want_bf16=True))
         if world == 1:
-            stages["knn_ms"], _ = stage_ms(lambda: ops.knn_topk(desc16, shard, a.k))
+            stages["knn_ms"], _ = stage_ms(lambda: gallery.search(desc16, a.k))
         stages["head_ms"], _ = stage_ms(lambda: head(desc))
 
         res = {
@@ -227,8 +241,8 @@ def main():
             "value": a.steps * a.batch * world / elapsed, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"DINOv2 {a.arch}/14 (random init) + SALAD + bf16 kNN k={a.k} over a "
+            "vs_baseline": None, "dtype": "bf16" if a.knn_dtype == "bf16" else "bf16 (backbone, SALAD) + fp8 e4m3 kNN", "data": "synthetic",
+            "config": {"workload": f"DINOv2 {a.arch}/14 (random init) + SALAD + {a.knn_dtype} kNN k={a.k} over a "
                                    f"{a.gallery}-row x {D_DESC} synthetic gallery sharded {world} way(s) + fused "
                                    f"(lat,lon,sin,cos) head; 3x224x224 bf16 images",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "gallery_rows": a.gallery,

@@ -184,3 +184,24 @@ def test_knn_fp8_agrees_with_bf16_on_planted_positives(dev):
     _, i8 = ops.knn_topk_fp8(q8, qs, g8, gs, 5)
     _, i16 = ops.knn_topk(qf.to(torch.bfloat16), gal.to(torch.bfloat16), 5)
     assert torch.equal(i8[:, 0].long(), pos) and torch.equal(i16[:, 0].long(), pos)
+
+
+def test_sharded_gallery_fp8_rows(dev):
+    """ShardedGallery with e4m3 rows + per-row scales: same answer as vpr_knn_topk_fp8 on the quantised
+    queries, and the planted neighbours are found (retrieval layer of BASELINE config 5)."""
+    from vpr_amd import ops
+    from vpr_amd.retrieval import ShardedGallery
+    g = torch.Generator().manual_seed(21)
+    N, B, D, k = 3000, 9, 8448, 5
+    gal = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    pos = torch.randint(0, N, (B,), generator=g)
+    q = torch.nn.functional.normalize(gal[pos] + 0.05 * torch.randn(B, D, generator=g), dim=1).to(torch.bfloat16).to(dev)
+    g8, gs = ops.quantize_fp8_rows(gal.to(dev))
+    sg = ShardedGallery(g8, N, 0, 1, scales=gs)
+    v, i = sg.search(q, k)
+    q8, qs = ops.quantize_fp8_rows(q.float())
+    v2, i2 = ops.knn_topk_fp8(q8, qs, g8, gs, k)
+    assert torch.equal(i, i2) and torch.equal(v, v2)
+    assert torch.equal(i[:, 0].cpu().long(), pos)
+    with pytest.raises(ValueError):
+        ShardedGallery(g8, N, 0, 1)                      # fp8 rows without scales

@@ -35,7 +35,7 @@ class VPRGeoPosePipeline:
         desc, desc16 = self.extractor.features(images, want_bf16=True)
         g = self.gallery
         q_all = g.gather_queries(desc16)
-        if self.knn_events is not None and g.world >= 1:
+        if self.knn_events is not None and g.world >= 1 and getattr(g, "scales", None) is None:
             # same kernels as ShardedGallery.search, with HIP events around the score kernel
             B = q_all.shape[0]
             ws = ops.knn_workspace(B, g.rows.shape[0], q_all.shape[1], self.k, q_all.device)
@@ -45,6 +45,16 @@ class VPRGeoPosePipeline:
             e1.record()
             self.knn_events.append((e0, e1))
             v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base)
+            if g.world > 1:
+                vs, is_ = all_gather_topk(v, i, g.world, g.group)
+                v, i = ops.topk_merge(vs, is_)
+        elif self.knn_events is not None:
+            # fp8 shard: events around the whole local search (quantise queries + scores + select)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            v, i = g.engine.local_topk(q_all, g.rows, self.k, g.index_base, g.scales)
+            e1.record()
+            self.knn_events.append((e0, e1))
             if g.world > 1:
                 vs, is_ = all_gather_topk(v, i, g.world, g.group)
                 v, i = ops.topk_merge(vs, is_)

@@ -27,7 +27,14 @@ def shard_bounds(N: int, rank: int, world: int) -> Tuple[int, int]:
 class HipEngine:
     """Local top-k and merge on the gfx950 kernels."""
 
-    def local_topk(self, q, gallery, k, index_base):
+    def local_topk(self, q, gallery, k, index_base, scales=None):
+        """bf16 shard: q bf16.  fp8 shard (uint8 rows + per-row f32 `scales`): the gathered queries are
+        quantised per row here (e4m3 + scale, vpr_quantize_fp8_rows) and searched by vpr_knn_topk_fp8."""
+        if gallery.dtype == torch.uint8:
+            if scales is None:
+                raise ValueError("fp8 shard needs per-row scales")
+            q8, qs = ops.quantize_fp8_rows(q.float())
+            return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base)
         return ops.knn_topk(q, gallery, k, index_base)
 
     def merge(self, vals, idxs):
@@ -48,10 +55,16 @@ def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
 
 class ShardedGallery:
     def __init__(self, local_rows: torch.Tensor, n_total: int, rank: int = 0, world: int = 1,
-                 engine=None, group: Optional[dist.ProcessGroup] = None):
+                 engine=None, group: Optional[dist.ProcessGroup] = None, scales: Optional[torch.Tensor] = None):
+        """local_rows: [n_local, D] bf16, or uint8 e4m3 bytes with per-row f32 `scales` (value = scale * fp8)."""
         lo, hi = shard_bounds(n_total, rank, world)
         if local_rows.shape[0] != hi - lo:
             raise ValueError(f"rank {rank}: shard has {local_rows.shape[0]} rows, expected {hi - lo}")
+        if (local_rows.dtype == torch.uint8) != (scales is not None):
+            raise ValueError("fp8 shards (uint8 rows) come with per-row scales, bf16 shards without")
+        if scales is not None and scales.numel() != hi - lo:
+            raise ValueError("scales: one per local row")
+        self.scales = scales
         self.rows, self.n_total, self.rank, self.world = local_rows, n_total, rank, world
         self.index_base = lo
         self.engine = engine if engine is not None else HipEngine()
@@ -66,7 +79,10 @@ class ShardedGallery:
 
     def search(self, q_all: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """q_all [B, D]: the same on every rank.  Returns merged (vals [B,k], idx [B,k]) on every rank."""
-        v, i = self.engine.local_topk(q_all, self.rows, k, self.index_base)
+        if self.scales is not None:
+            v, i = self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales)
+        else:
+            v, i = self.engine.local_topk(q_all, self.rows, k, self.index_base)
         if self.world == 1:
             return v, i
         B = q_all.shape[0]
