@@ -39,6 +39,17 @@ def test_bench_single_rank_contract(dev):
     assert d["recall_at_1"] == 1.0 and "workload" in d["config"]
 
 
+def test_bench_fp8_gallery(dev):
+    """--knn-dtype fp8: e4m3 shard + per-row scales through the same pipeline; planted neighbours still found."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--knn-dtype", "fp8",
+                        "--no-cpu-baseline"] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    assert REQUIRED <= set(d) and "fp8" in d["dtype"] and "fp8 kNN" in d["config"]["workload"]
+    assert d["roofline"]["algorithmic_bytes"] == 3000 * 8448 + 8 * 8448 + 8 * 10 * 8
+    assert d["value"] > 0 and d["recall_at_1"] == 1.0
+
+
 def test_bench_two_ranks_gloo_rehearsal(dev):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
