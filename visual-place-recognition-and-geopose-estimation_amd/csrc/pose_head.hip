@@ -105,34 +105,43 @@ __global__ __launch_bounds__(256) void pose_epilogue_kernel(
     const float* __restrict__ part, int nslice, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ out,
     int B, int hidden, int n_out, int sincos_offset) {
-  __shared__ float red[4];
+  __shared__ float red[8][4];
   __shared__ float outs[8];
   const int b = blockIdx.x;
   float po[8];
 #pragma unroll
   for (int o = 0; o < 8; ++o) po[o] = 0.f;
-  for (int h = threadIdx.x; h < hidden; h += 256) {
-    float s = 0.f;
-    for (int ks0 = 0; ks0 < nslice; ks0 += 8) {   // 8 independent loads in flight, summed in slice order
-      float t[8];
+  // a thread owns 4 consecutive hidden units: one float4 per slab, all slabs of a group of 16 requested
+  // together (hidden = 1024, 16 slabs: a single round trip), summed in slice order
+  for (int h = threadIdx.x * 4; h < hidden; h += 1024) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ks0 = 0; ks0 < nslice; ks0 += 16) {
+      float4 t[16];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = part[((long long)min(ks0 + i, nslice - 1) * B + b) * hidden + h];
+      for (int i = 0; i < 16; ++i)
+        t[i] = *reinterpret_cast<const float4*>(part + ((long long)min(ks0 + i, nslice - 1) * B + b) * hidden + h);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (ks0 + i < nslice) s += t[i];
+      for (int i = 0; i < 16; ++i)
+        if (ks0 + i < nslice) { s.x += t[i].x; s.y += t[i].y; s.z += t[i].z; s.w += t[i].w; }
     }
-    s = fmaxf(s + b1[h], 0.f);
+    const float4 bb = *reinterpret_cast<const float4*>(b1 + h);
+    s.x = fmaxf(s.x + bb.x, 0.f); s.y = fmaxf(s.y + bb.y, 0.f); s.z = fmaxf(s.z + bb.z, 0.f); s.w = fmaxf(s.w + bb.w, 0.f);
 #pragma unroll
     for (int o = 0; o < 8; ++o)
-      if (o < n_out) po[o] = fmaf(s, W2[(long long)o * hidden + h], po[o]);
+      if (o < n_out) {
+        const float4 w = *reinterpret_cast<const float4*>(W2 + (long long)o * hidden + h);
+        po[o] = fmaf(s.x, w.x, fmaf(s.y, w.y, fmaf(s.z, w.z, fmaf(s.w, w.w, po[o]))));
+      }
   }
+  // all outputs reduced together: wave sums, one barrier, fixed order
 #pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    if (o < n_out) {   // n_out is uniform: every thread takes the same branches
-      const float tot = block_sum_256p(po[o], red);
-      if (threadIdx.x == 0) outs[o] = tot + b2[o];
+  for (int o = 0; o < 8; ++o)
+    if (o < n_out) {   // n_out is uniform
+      const float v = wave_sum(po[o]);
+      if ((threadIdx.x & 63) == 0) red[o][threadIdx.x >> 6] = v;
     }
-  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_out) outs[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]) + b2[threadIdx.x];
   __syncthreads();
   finish_outputs(outs, n_out, sincos_offset, out + (long long)b * n_out);
 }
@@ -275,73 +284,104 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8&
   }
 }
 
-// grid (hidden / 64, nslice, ceil(B / 64)); workgroup = 64 hidden units x 64 batch rows x one K slice; wave w owns
-// hidden units 16w .. 16w+15 (its own accumulators, no cross-wave reduction), the four waves read the same x
-// fragments (L1 hits), so x crosses the L2 once per 64 hidden units (16 per workgroup cost 138 MB of L2 reads).
-__global__ __launch_bounds__(256) void pose_l1_split_kernel(
+// grid (hidden / 64, nslice, ceil(B / 64)); workgroup = 64 hidden units x 64 batch rows x one K slice.  The four
+// waves split the slice's K-steps (each wave: all 4 hidden blocks x all 4 batch blocks = 16 accumulators), so a
+// wave's part is two or three memory round trips of 32 x 16-byte loads, x crosses the L2 once per 64 hidden
+// units, and one workgroup per CU keeps 128 KB in flight.  Partial accumulators meet in LDS; wave w finishes
+// hidden block w.
+__global__ __launch_bounds__(256, 1) void pose_l1_split_kernel(
     const float* __restrict__ x, const uint16_t* __restrict__ Whi, const uint16_t* __restrict__ Wlo,
     float* __restrict__ part, int B, int D, int hidden, int steps_per_slice) {
+  extern __shared__ __attribute__((aligned(16))) float red[];        // [4 waves][4 cb][4 mb][64 lanes][4] = 64 KB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 64 + wave * 16, ks = blockIdx.y, m0 = blockIdx.z * 64;
+  const int n0 = blockIdx.x * 64, ks = blockIdx.y, m0 = blockIdx.z * 64;
   const int ksteps = D >> 5;
-  const int kbeg = ks * steps_per_slice, kend = min(ksteps, kbeg + steps_per_slice);
-  const long long wrow = (long long)min(n0 + r, hidden - 1) * D + 8 * g;
+  const int s_begin = ks * steps_per_slice, s_end = min(ksteps, s_begin + steps_per_slice);
+  const int ns = max(s_end - s_begin, 0);
+  const int kbeg = s_begin + ns * wave / 4, kend = s_begin + ns * (wave + 1) / 4;
+  long long wrow[4];
   const float* xp[4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) xp[mb] = x + (long long)min(m0 + mb * 16 + r, B - 1) * D + 8 * g;
-  f32x4 acc[4];
+  for (int i = 0; i < 4; ++i) {
+    wrow[i] = (long long)min(n0 + i * 16 + r, hidden - 1) * D + 8 * g;
+    xp[i] = x + (long long)min(m0 + i * 16 + r, B - 1) * D + 8 * g;
+  }
+  f32x4 acc[4][4];     // [cb][mb]
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mac = [&](const bf16x8& wh, const bf16x8& wl, const float4& xa, const float4& xb, f32x4& c) {
-    bf16x8 xh, xl;
-    split8(xa, xb, xh, xl);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl, c, 0, 0, 0);     // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
-  };
-  int s = kbeg;
-  for (; s + 2 <= kend; s += 2) {               // two K-steps per round trip: 20 x 16-byte loads in flight per lane
-    bf16x8 wh[2], wl[2];
-    float4 xa[2][4], xb[2][4];
+  for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      wh[u] = *reinterpret_cast<const bf16x8*>(Whi + wrow + (s + u) * 32);
-      wl[u] = *reinterpret_cast<const bf16x8*>(Wlo + wrow + (s + u) * 32);
+    for (int mb = 0; mb < 4; ++mb) acc[cb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](const bf16x8 (&wh)[4], const bf16x8 (&wl)[4], const float4 (&xa)[4], const float4 (&xb)[4]) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        xa[u][mb] = *reinterpret_cast<const float4*>(xp[mb] + (s + u) * 32);
-        xb[u][mb] = *reinterpret_cast<const float4*>(xp[mb] + (s + u) * 32 + 4);
+    for (int mb = 0; mb < 4; ++mb) {
+      bf16x8 xh, xl;
+      split8(xa[mb], xb[mb], xh, xl);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        f32x4 c = acc[cb][mb];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[cb], xl, c, 0, 0, 0);     // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[cb], xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[cb], xl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[cb], xh, c, 0, 0, 0);
+        acc[cb][mb] = c;
       }
     }
+  };
+  int s = kbeg;
+  for (; s + 2 <= kend; s += 2) {               // two K-steps per round trip: 32 x 16-byte loads in flight per lane
+    bf16x8 wh[2][4], wl[2][4];
+    float4 xa[2][4], xb[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) mac(wh[u], wl[u], xa[u][mb], xb[u][mb], acc[mb]);
+      for (int i = 0; i < 4; ++i) {
+        wh[u][i] = *reinterpret_cast<const bf16x8*>(Whi + wrow[i] + (s + u) * 32);
+        wl[u][i] = *reinterpret_cast<const bf16x8*>(Wlo + wrow[i] + (s + u) * 32);
+        xa[u][i] = *reinterpret_cast<const float4*>(xp[i] + (s + u) * 32);
+        xb[u][i] = *reinterpret_cast<const float4*>(xp[i] + (s + u) * 32 + 4);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) compute(wh[u], wl[u], xa[u], xb[u]);
   }
   for (; s < kend; ++s) {
-    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(Whi + wrow + s * 32);
-    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(Wlo + wrow + s * 32);
+    bf16x8 wh[4], wl[4];
+    float4 xa[4], xb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wh[i] = *reinterpret_cast<const bf16x8*>(Whi + wrow[i] + s * 32);
+      wl[i] = *reinterpret_cast<const bf16x8*>(Wlo + wrow[i] + s * 32);
+      xa[i] = *reinterpret_cast<const float4*>(xp[i] + s * 32);
+      xb[i] = *reinterpret_cast<const float4*>(xp[i] + s * 32 + 4);
+    }
+    compute(wh, wl, xa, xb);
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
-      mac(wh, wl, *reinterpret_cast<const float4*>(xp[mb] + s * 32), *reinterpret_cast<const float4*>(xp[mb] + s * 32 + 4), acc[mb]);
-  }
-  // C/D: col = batch row (lane & 15) of block mb, rows 4g+e = 4 consecutive hidden units
-  if (n0 + 4 * g < hidden) {
+      *reinterpret_cast<f32x4*>(red + ((((wave * 4 + cb) * 4 + mb) * 64 + lane) << 2)) = acc[cb][mb];
+  __syncthreads();
+  // wave w finishes hidden block w; C/D: col = batch row (lane & 15) of block mb, rows 4g+e = 4 consecutive hidden units
+  const int n = n0 + wave * 16 + 4 * g;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int m = m0 + mb * 16 + r;
-      if (m < B) *reinterpret_cast<f32x4*>(part + ((long long)ks * B + m) * hidden + n0 + 4 * g) = acc[mb];
+  for (int mb = 0; mb < 4; ++mb) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(red + ((((0 * 4 + wave) * 4 + mb) * 64 + lane) << 2));
+#pragma unroll
+    for (int p = 1; p < 4; ++p) {               // fixed order: bitwise reproducible
+      const f32x4 q = *reinterpret_cast<const f32x4*>(red + ((((p * 4 + wave) * 4 + mb) * 64 + lane) << 2));
+      t[0] += q[0]; t[1] += q[1]; t[2] += q[2]; t[3] += q[3];
     }
+    const int m = m0 + mb * 16 + r;
+    if (m < B && n < hidden) *reinterpret_cast<f32x4*>(part + ((long long)ks * B + m) * hidden + n) = t;
   }
 }
 
 static int pick_slices_split(int B, int D, int hidden) {
-  // ~512-768 workgroups; a slice at least 4 K-steps (two round trips)
+  // about one workgroup per CU; a slice at least 8 K-steps (two per wave)
   const int tiles = ((hidden + 63) / 64) * ((B + 63) / 64);
-  int ks = (640 + tiles - 1) / tiles;
-  const int max_ks = (D / 32) / 4 > 0 ? (D / 32) / 4 : 1;
+  int ks = (256 + tiles - 1) / tiles;
+  const int max_ks = (D / 32) / 8 > 0 ? (D / 32) / 8 : 1;
   if (ks > max_ks) ks = max_ks;
   if (ks > 32) ks = 32;
   if (ks < 1) ks = 1;
@@ -459,7 +499,17 @@ extern "C" int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const 
   const int ksteps = D / 32;
   const int sps = (ksteps + ks - 1) / ks;
   float* part = static_cast<float*>(workspace);
-  VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), 0, stream, x,
+  constexpr size_t l1_lds = 4 * 4 * 4 * 64 * 4 * sizeof(float);   // 64 KB
+  {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(pose_l1_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)l1_lds) != hipSuccess)
+        return VPR_ERR_LAUNCH;
+      attr = true;
+    }
+  }
+  VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), l1_lds, stream, x,
                                W1_hi, W1_lo, part, B, D, hidden, sps));
   VPR_TRY_LAUNCH(launch_kernel(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
                                hidden, n_out, sincos_offset));
