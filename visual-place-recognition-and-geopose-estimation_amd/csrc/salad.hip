@@ -6,16 +6,18 @@
 // published algorithm and tests/test_salad*.py pin both against closed-form known answers.
 //
 // Stages (one stream):
-//   launch 1 (grouped GEMM)  H  = relu(X W1_sc^T + b1)  [B*n, 2*hidden] bf16  score+cluster layer 1 fused
-//                            Ht = relu(cls W1_t^T + b1_t)  [B, hidden] bf16
-//   launch 2 (grouped GEMM)  S  = H[:, :hidden] W2_s^T + b2_s   [B*n, m] f32
+//   skinny_linear_kernel     Ht = relu(cls W1_t^T + b1_t)  [B, hidden] bf16           token-MLP layer 1
+//   gemm256_kernel           H  = relu(X W1_sc^T + b1)  [B*n, 2*hidden] bf16           score+cluster layer 1 fused
+//   gemm_nt_group_kernel     S  = H[:, :hidden] W2_s^T + b2_s   [B*n, m] f32
 //                            F  = H[:, hidden:] W2_c^T + b2_c   [B*n, l] f32
 //                            g  = Ht W2_t^T + b2_t              [B, t] f32
-//   sinkhorn_aggregate_kernel (one workgroup per image): dustbin row, log-domain Sinkhorn in
-//   (v_exp_f32 / v_log_f32 forms: ~1e-6 relative, far inside the 1e-4 descriptor tolerance)
-//   LDS (row LSE: one wave per row + shuffles; column LSE: one thread per column), P = exp(.),
-//   V = F^T P^T on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), the three L2 normalisations,
-//   8448 outputs (f32 + bf16 copy for the kNN stage).
+//   sinkhorn_aggregate_kernel (one workgroup per image): dustbin row, log-domain Sinkhorn in LDS
+//   (v_exp_f32 / v_log_f32 forms: ~1e-6 relative, far inside the 1e-4 descriptor tolerance; row LSE: one
+//   16-lane DPP group per row; column LSE: one thread per column), P = exp(.) as two bf16 planes,
+//   V = F^T P^T as four exact-product bf16 MFMAs on the (hi, lo) terms (f32 accuracy), the three L2
+//   normalisations, 8448 outputs (f32 + bf16 copy for the kNN stage).
+//   (Tried: 8 waves per image — the Sinkhorn iterations are exp/LDS-issue-bound per SIMD, not latency-bound:
+//   4.7 us per iteration instead of 3.4.)
 #include <math.h>
 #include "vpr_common.cuh"
 #include "vpr_internal.h"
@@ -27,6 +29,8 @@ constexpr int SA_M = 64;    // clusters
 constexpr int SA_L = 128;   // cluster dim
 constexpr int SA_T = 256;   // token dim
 constexpr int SA_LD = SA_N + 1;   // LDS row stride (words) of the [m+1][n] score matrix
+constexpr int SA_PLD = SA_N + 8;  // row stride (bf16) of the P planes: 528 B, 16-byte aligned rows, rows 4 banks apart
+constexpr size_t SA_PLANES_OFF = (((SA_M + 1) * SA_LD + 68 + SA_N + 4 * SA_M + 4) * sizeof(float) + 15) / 16 * 16;
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // deterministic: wave butterflies, then a fixed-order sum of the 4 wave totals
@@ -37,7 +41,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
+__global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     const float* __restrict__ scores,   // [B, n, m]
     const float* __restrict__ feats,    // [B, n, l]
     const float* __restrict__ tokfeat,  // [B, t]
@@ -49,6 +53,8 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
   float* v = u + 68;                                 // [256]
   float* ssq = v + SA_N;                             // [4][64]
   float* red = ssq + 4 * SA_M;                       // [4]
+  uint16_t* Phi = reinterpret_cast<uint16_t*>(smem + SA_PLANES_OFF);   // [64][SA_PLD] bf16: hi plane of P (16-byte aligned)
+  uint16_t* Plo = Phi + SA_M * SA_PLD;                    // lo plane: P = hi + lo to 2^-17
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int D_OUT = SA_T + SA_L * SA_M;
@@ -80,52 +86,82 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
   const float log_a_dust = logf((float)(SA_N - SA_M)) - log_nm;
   const float log_b = -log_nm;
 
+  // The score matrix does not change across iterations (only u and v do): every thread keeps its operands of
+  // both half-steps in registers — its column (65 values) and its 16 entries of each of its 5 rows — so the
+  // iterations touch LDS only for u and v.  (One wave per SIMD: the 512-register budget is free anyway.)
+  const int grp = tid >> 4, l16 = tid & 15;
+  float mrow[5][16], mcol[SA_M + 1];
+#pragma unroll
+  for (int p5 = 0; p5 < 5; ++p5) {
+    const int ic = min(16 * p5 + grp, SA_M);        // clamp (EXEC stays full for the DPP steps)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) mrow[p5][c] = Mx[ic * SA_LD + l16 + 16 * c];
+  }
+#pragma unroll
+  for (int i = 0; i <= SA_M; ++i) mcol[i] = Mx[i * SA_LD + tid];
+
   for (int it = 0; it < iters; ++it) {
     // u_i = log_a_i - LSE_j(M_ij + v_j): one 16-lane row group per matrix row (16 rows of the
     // matrix in flight per workgroup), 16 columns per lane, DPP-only reductions.
     {
-      const int grp = tid >> 4, l16 = tid & 15;
-      for (int i0 = 0; i0 <= SA_M; i0 += 16) {
-        const int i = i0 + grp;
-        const int ic = i <= SA_M ? i : SA_M;      // clamp (EXEC stays full for the DPP steps)
+      float vv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) vv[c] = v[l16 + 16 * c];
+#pragma unroll
+      for (int p5 = 0; p5 < 5; ++p5) {
+        const int i = 16 * p5 + grp;
         float x[16];
         float mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          x[c] = Mx[ic * SA_LD + l16 + 16 * c] + v[l16 + 16 * c];
+          x[c] = mrow[p5][c] + vv[c];
           mx = fmaxf(mx, x[c]);
         }
         mx = row16_max(mx);
-        float s = 0.f;
+        float sx = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s += __expf(x[c] - mx);
-        s = row16_sum(s);
-        if (l16 == 0 && i <= SA_M) u[i] = (i == SA_M ? log_a_dust : log_a) - (mx + __logf(s));
+        for (int c = 0; c < 16; ++c) sx += __expf(x[c] - mx);
+        sx = row16_sum(sx);
+        if (l16 == 0 && i <= SA_M) u[i] = (i == SA_M ? log_a_dust : log_a) - (mx + __logf(sx));
       }
     }
     __syncthreads();
     // v_j = log_b - LSE_i(M_ij + u_i): thread per column
     {
-      const int j = tid;
+      float x[SA_M + 1];
       float mx = -INFINITY;
-      for (int i = 0; i <= SA_M; ++i) mx = fmaxf(mx, Mx[i * SA_LD + j] + u[i]);
-      float s = 0.f;
-      for (int i = 0; i <= SA_M; ++i) s += __expf(Mx[i * SA_LD + j] + u[i] - mx);
-      v[j] = log_b - (mx + __logf(s));
+#pragma unroll
+      for (int i = 0; i <= SA_M; ++i) { x[i] = mcol[i] + u[i]; mx = fmaxf(mx, x[i]); }
+      float sx = 0.f;
+#pragma unroll
+      for (int i = 0; i <= SA_M; ++i) sx += __expf(x[i] - mx);
+      v[tid] = log_b - (mx + __logf(sx));
     }
     __syncthreads();
   }
 
-  // ---- P = exp(M + u + v - norm), norm = -log(n+m); dustbin row dropped ----
+  // ---- P = exp(M + u + v - norm), norm = -log(n+m); dustbin row dropped.  Stored as two bf16 planes
+  // (hi = bf16(P), lo = bf16(P - hi)) for the aggregation below. ----
   {
     const int j = tid;
     const float vj = v[j] + log_nm;
-    for (int i = 0; i < SA_M; ++i) Mx[i * SA_LD + j] = __expf(Mx[i * SA_LD + j] + u[i] + vj);
+#pragma unroll
+    for (int i = 0; i < SA_M; ++i) {
+      const float pv = __expf(mcol[i] + u[i] + vj);
+      const __bf16 h = (__bf16)pv;
+      const __bf16 l = (__bf16)(pv - (float)h);
+      Phi[i * SA_PLD + j] = __builtin_bit_cast(uint16_t, h);
+      Plo[i * SA_PLD + j] = __builtin_bit_cast(uint16_t, l);
+    }
   }
   __syncthreads();
 
-  // ---- V[l][m] = sum_j F[j][l] * P[m][j] on the exact-f32 MFMA ----
-  // 32x32x2 operand maps: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31].
+  // ---- V[l][m] = sum_j F[j][l] * P[m][j] on the bf16 matrix pipe at f32 accuracy ----
+  // The exact-f32 MFMA (v_mfma_f32_32x32x2_f32) needs 16.4k cycles per SIMD for this 4.2 MFLOP product — it was
+  // the longest phase of the kernel.  With F and P each split into two bf16 terms (2^-17 relative), the product
+  // is four v_mfma_f32_32x32x16_bf16 with exact products and f32 accumulation: 4.1k cycles, error <= 2^-16 per
+  // product (~1e-8 absolute on descriptor entries of 1e-2; tolerance 1e-4).
+  // 32x32x16 operand maps: A[i = lane&31][k = 8*(lane>>5) + e], B[k = 8*(lane>>5) + e][j = lane&31].
   // Wave w owns cluster-dim rows l0 = 32w .. 32w+31 and both 32-cluster column blocks.
   const float* fb = feats + (long long)b * SA_N * SA_L;
   const int l0 = 32 * wave;
@@ -133,24 +169,38 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
   const int kh = lane >> 5, li = lane & 31;
-  // F comes straight from L2/HBM (32 KB per wave, each value used once): 16 k-steps per chunk,
-  // the next chunk's 16 loads are in flight while the current chunk's 32 MFMAs run.
+  // F comes straight from L2 (32 KB per wave, each value used once): 2 k-steps (32 tokens) per chunk,
+  // the next chunk's 16 loads are in flight while the current chunk's 16 MFMAs run.
   float a_cur[16], a_nxt[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) a_cur[i] = fb[(2 * i + kh) * SA_L + l0 + li];
+  for (int i = 0; i < 16; ++i) a_cur[i] = fb[(16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
 #pragma unroll
   for (int ch = 0; ch < SA_N / 32; ++ch) {
     if (ch + 1 < SA_N / 32) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a_nxt[i] = fb[(2 * (16 * (ch + 1) + i) + kh) * SA_L + l0 + li];
+      for (int i = 0; i < 16; ++i) a_nxt[i] = fb[(32 * (ch + 1) + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int j = 2 * (16 * ch + i) + kh;
-      const float p0 = Mx[li * SA_LD + j];
-      const float p1 = Mx[(32 + li) * SA_LD + j];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], p0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], p1, acc1, 0, 0, 0);
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 fh, fl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fh[e] = (__bf16)a_cur[8 * st + e];
+        fl[e] = (__bf16)(a_cur[8 * st + e] - (float)fh[e]);
+      }
+      const int j0 = 32 * ch + 16 * st + 8 * kh;
+      const bf16x8 p0h = *reinterpret_cast<const bf16x8*>(Phi + li * SA_PLD + j0);
+      const bf16x8 p0l = *reinterpret_cast<const bf16x8*>(Plo + li * SA_PLD + j0);
+      const bf16x8 p1h = *reinterpret_cast<const bf16x8*>(Phi + (32 + li) * SA_PLD + j0);
+      const bf16x8 p1l = *reinterpret_cast<const bf16x8*>(Plo + (32 + li) * SA_PLD + j0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p0l, acc0, 0, 0, 0);     // smallest terms first
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p1l, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p1h, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p0l, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p1l, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p1h, acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) a_cur[i] = a_nxt[i];
@@ -204,7 +254,7 @@ __global__ __launch_bounds__(256) void sinkhorn_aggregate_kernel(
   }
 }
 
-constexpr size_t SINKHORN_LDS = ((SA_M + 1) * SA_LD + 68 + SA_N + 4 * SA_M + 4) * sizeof(float);
+constexpr size_t SINKHORN_LDS = SA_PLANES_OFF + 2 * (size_t)SA_M * SA_PLD * sizeof(uint16_t);
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
