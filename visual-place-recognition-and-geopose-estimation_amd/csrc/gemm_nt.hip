@@ -17,7 +17,7 @@ namespace vpr {
 
 struct GemmGroup { GemmProblem p[GEMM_MAX_GROUP]; int count; };
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int STAGES = 2>
 __device__ __forceinline__ void gemm_nt_tile(const GemmProblem& pr, int orig, char* smem) {
   constexpr int BM = 128;
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
@@ -87,14 +87,25 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmProblem& pr, int orig, ch
     for (int i = 0; i < BG; ++i) glds16(w_src[i] + ks * 64, tw + (wave + 4 * i) * 8 * TILE_ROW_BYTES);
   };
 
-  stage(0, 0);
+  // STAGES-deep ring, STAGES-1 K-tiles in flight.  Before the barrier of step ks, tile ks must have landed:
+  // the (STAGES-2) tiles issued after it may stay outstanding (counted vmcnt; every thread issues AG + BG
+  // LDS-DMA instructions per tile).  In the tail fewer tiles follow, so the wait degrades to vmcnt(0).
+  constexpr int LOADS_PER_STAGE = AG + BG;
+#pragma unroll
+  for (int p = 0; p < STAGES - 1; ++p)
+    if (p < nk) stage(p, p);
   for (int ks = 0; ks < nk; ++ks) {
-    // Own LDS-DMA drained, then the barrier: stage ks has landed for every wave and every wave
-    // is done reading buffer (ks+1)&1.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAGES > 2 && ks + STAGES - 2 < nk) {
+      if constexpr (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS_PER_STAGE) : "memory");
+      else if constexpr (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LOADS_PER_STAGE) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ... then the barrier: tile ks has landed for every wave and every wave is done reading the buffer
+    // that the next issue overwrites (the one read at step ks-1).
     __syncthreads();
-    if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
-    const char* ta = smem + (ks & 1) * STAGE_BYTES;
+    if (ks + STAGES - 1 < nk) stage((ks + STAGES - 1) % STAGES, ks + STAGES - 1);
+    const char* ta = smem + (ks % STAGES) * STAGE_BYTES;
     const char* tw = ta + BM * TILE_ROW_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem pr) {
 // Several independent small GEMMs in one launch (the SALAD layer-2 / token-MLP GEMMs are a few
 // tiles each: as separate launches each costs a full launch + K-loop latency with the chip idle).
 // Workgroup ids are dealt to the problems in order; every problem keeps its own XCD remap.
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(256, 2) void gemm_nt_group_kernel(GemmGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int id = blockIdx.x;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_group_kernel(GemmGroup grp) {
   for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
     if (i < grp.count) {
       const int n = grp.p[i].tiles_m * grp.p[i].tiles_n;
-      if (id >= 0 && id < n) { gemm_nt_tile<BN, WM, WN>(grp.p[i], id, smem); id = -1; }
+      if (id >= 0 && id < n) { gemm_nt_tile<BN, WM, WN, STAGES>(grp.p[i], id, smem); id = -1; }
       else if (id >= 0) id -= n;
     }
   }
@@ -200,8 +211,33 @@ int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream
     total += grp.p[i].tiles_m * grp.p[i].tiles_n;
   }
   for (int i = count; i < GEMM_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+  // The grouped problems are short (K = 512: 8 K-tiles) and about one workgroup per CU: with the 2-deep ring each
+  // K-step waits out one full memory round trip.  Variant 1 keeps two tiles in flight (3-deep ring) on 128 x 64
+  // tiles (72 KB of LDS: still two workgroups per CU, so the ~390 workgroups stay one resident round; a 3-deep
+  // ring on 128 x 128 tiles is 96 KB = one workgroup per CU and 258 workgroups then need a second round:
+  // measured 101.6 vs 88.9 us for the whole SALAD stage).
+  const char* senv = getenv("VPR_GEMM_GROUP_VARIANT");     // A/B switch
+  const int variant = senv ? atoi(senv) : 1;              // 0 = 128 x 128 tiles, 2-deep ring (89.9 us); 1 = default (84.4 us)
+  if (variant == 1) {
+    total = 0;
+    for (int i = 0; i < count; ++i) {
+      grp.p[i].tiles_n = (grp.p[i].N + 63) / 64;
+      total += grp.p[i].tiles_m * grp.p[i].tiles_n;
+    }
+    for (int i = count; i < GEMM_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    constexpr size_t lds3 = 3 * (128 + 64) * TILE_ROW_BYTES;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_group_kernel<64, 4, 1, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+        return VPR_ERR_LAUNCH;
+      attr = true;
+    }
+    VPR_TRY_LAUNCH(launch_kernel((gemm_nt_group_kernel<64, 4, 1, 3>), dim3(total), dim3(256), lds3, stream, grp));
+    return VPR_OK;
+  }
   constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
-  VPR_TRY_LAUNCH(launch_kernel((gemm_nt_group_kernel<128, 2, 2>), dim3(total), dim3(256), lds, stream, grp));
+  VPR_TRY_LAUNCH(launch_kernel((gemm_nt_group_kernel<128, 2, 2, 2>), dim3(total), dim3(256), lds, stream, grp));
   return VPR_OK;
 }
 
