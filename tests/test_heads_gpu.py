@@ -120,7 +120,8 @@ def test_add_layernorm_equals_add_then_layernorm(dev):
 
 
 @pytest.mark.parametrize("B,Cin,H,W,P,kpad,lead", [(3, 3, 224, 224, 14, 640, 1), (2, 3, 224, 224, 14, 592, 0),
-                                                    (1, 1, 32, 64, 8, 64, 2), (2, 3, 64, 32, 16, 768, 1)])
+                                                    (1, 1, 32, 64, 8, 64, 2), (2, 3, 64, 32, 16, 768, 1),
+                                                    (2, 3, 14, 56, 7, 152, 1)])      # odd patch: 2-byte LDS path
 def test_patchify_matches_unfold(dev, B, Cin, H, W, P, kpad, lead):
     """Bit-exact vs F.unfold (the conv's im2col order c*P*P + i*P + j), zero cls rows and K padding."""
     from vpr_amd import ops

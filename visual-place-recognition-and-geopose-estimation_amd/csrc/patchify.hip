@@ -33,19 +33,38 @@ __global__ __launch_bounds__(256) void patchify_kernel(const uint16_t* __restric
   const int K = Cin * P * P;
   const int kchunks = kpad >> 3;
   const long long row0 = (long long)b * (lead + GH * G) + lead + (long long)py * G;
+  const bool pairs = ((P | W) & 1) == 0;      // even P, W: k even <=> j even, so elements (k, k+1) share a 4-byte LDS word
   for (int t = threadIdx.x; t < G * kchunks; t += blockDim.x) {
     const int px = t / kchunks, kc = t - px * kchunks;
     s16x8 o;
+    if (pairs) {
+      const uint32_t* rows32 = reinterpret_cast<const uint32_t*>(rows);
+      uint32_t w4[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = kc * 8 + e;
-      short v = 0;
-      if (k < K) {
-        const int c = k / (P * P), r = k - c * P * P;
-        const int i = r / P, j = r - i * P;
-        v = (short)rows[(c * P + i) * W + px * P + j];
+      for (int q = 0; q < 4; ++q) {
+        const int k = kc * 8 + 2 * q;
+        uint32_t v = 0;
+        if (k < K) {
+          const int c = k / (P * P), r = k - c * P * P;
+          const int i = r / P, j = r - i * P;
+          v = rows32[((c * P + i) * W + px * P + j) >> 1];
+        }
+        w4[q] = v;
       }
-      o[e] = v;
+      const uint4 u4 = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      o = __builtin_bit_cast(s16x8, u4);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kc * 8 + e;
+        short v = 0;
+        if (k < K) {
+          const int c = k / (P * P), r = k - c * P * P;
+          const int i = r / P, j = r - i * P;
+          v = (short)rows[(c * P + i) * W + px * P + j];
+        }
+        o[e] = v;
+      }
     }
     *reinterpret_cast<s16x8*>(out + (row0 + px) * kpad + kc * 8) = o;
   }
