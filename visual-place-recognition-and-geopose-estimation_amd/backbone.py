@@ -165,6 +165,13 @@ class DinoV2(nn.Module):
             self._embed_w, self._embed_off, self._embed_key = w, off, key
         return self._embed_w, self._embed_off
 
+    def _raw_tokens(self, M: int, Mp: int, C: int, dev: torch.device) -> torch.Tensor:
+        buf = getattr(self, "_raw_buf", None)
+        if buf is None or buf.shape != (M, C) or buf.device != dev:
+            buf = torch.zeros((M, C), dtype=torch.bfloat16, device=dev)
+            self._raw_buf = buf
+        return buf
+
     def _forward_hip_split(self, img: torch.Tensor) -> "SplitTokens":
         """The whole backbone on the GPU in the split row layout [B*n patch rows | B cls rows]:
         every linear layer runs as one library GEMM over the B*n patch rows — at n = 256 an exact
@@ -186,9 +193,8 @@ class DinoV2(nn.Module):
         dev, bf = img.device, torch.bfloat16
         w, off = self._embed_consts(img)
         a = ops.patchify_bf16(img.contiguous(), P, w.shape[1], 0)               # [Mp, kpad]
-        raw = torch.empty((M, C), dtype=bf, device=dev)
+        raw = self._raw_tokens(M, Mp, C, dev)       # persistent: its cls rows are zero and nothing ever writes them
         torch.mm(a, w.t(), out=raw[:Mp])
-        raw[Mp:].zero_()
         blocks = self.blocks
         n0 = blocks[0].norm1
         x, h = ops.add_layernorm_bf16(raw, off, n0.weight, n0.bias, n0.eps)
