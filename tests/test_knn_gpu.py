@@ -159,7 +159,29 @@ def test_quantize_fp8_matches_torch(dev):
     assert torch.equal(q.cpu(), q_ref)
 
 
-@pytest.mark.parametrize("B,N,D,k", [(64, 3000, 8448, 10), (5, 300, 128, 3), (70, 9000, 1024, 20)])
+def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch):
+    """More than 64 queries: the block-scaled fp8 MFMA GEMM (v_mfma_scale_f32_32x32x64_f8f6f4) must produce the
+    score matrix the streaming kernel produces (same exact fp8 products, different f32 summation order)."""
+    from vpr_amd import ops, _lib
+    import ctypes
+    B, N, D, k = 200, 3001, 8448, 10
+    q, qs = _fp8_rows(B, D, 41)
+    g, gs = _fp8_rows(N, D, 42)
+    q, qs, g, gs = q.to(dev), qs.to(dev), g.to(dev), gs.to(dev)
+    outs = []
+    for thr in ("100000", "65"):
+        monkeypatch.setenv("VPR_KNN_GEMM_MIN_B", thr)
+        ws = ops.knn_workspace(B, N, D, k, dev)
+        ws.zero_()
+        v, i = ops.knn_topk_fp8(q, qs, g, gs, k, 0, ws)
+        outs.append((ops.knn_scores_view(ws, B, N, D, k).clone(), v, i))
+    (s_stream, v0, i0), (s_gemm, v1, i1) = outs
+    scale = s_stream.abs().max().item()
+    assert (s_stream - s_gemm).abs().max().item() < 2e-6 * max(scale, 1.0)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)              # exact rescoring makes the final answer identical
+
+
+@pytest.mark.parametrize("B,N,D,k", [(64, 3000, 8448, 10), (5, 300, 128, 3), (70, 9000, 1024, 20), (300, 4000, 8448, 10)])
 def test_knn_fp8_matches_oracle(dev, B, N, D, k):
     """BASELINE config 5 arithmetic (e4m3 descriptors, per-row scale) at oracle-sized N."""
     from vpr_amd import ops

@@ -168,6 +168,125 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_group_kernel(GemmGroup grp) {
   }
 }
 
+// ---- fp8 (OCP e4m3, per-row f32 scales) variant: C[m][n] = a_scale[m] * w_scale[n] * sum_k A[m][k] W[n][k] ----
+// The kNN score tile for more than 64 gathered queries against an e4m3 shard (BASELINE config 5 on several GPUs).
+// Same 128 x 128 tile, LDS image and 2-deep LDS-DMA ring as gemm_nt_tile — a 128-byte tile row is now 128 K
+// values — but the products run on the block-scaled matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4 with
+// unit (E8M0 = 127) scales: twice the bf16 rate, where the plain fp8 MFMA runs at the bf16 rate.  A lane's
+// operand is 32 contiguous K bytes (two swizzled 16-byte chunks); A and B use the same lane -> K assignment,
+// which is all a dot product needs.
+struct GemmFp8Problem {
+  const uint8_t* A; int lda; const uint8_t* W; int ldw; const float* a_scale; const float* w_scale;
+  float* C; int ldc; int M, N, K, tiles_m, tiles_n;
+};
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_fp8_kernel(GemmFp8Problem pr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 128, BN = 128, WN = 2, TM = 2, TN = 2;      // 2 x 2 waves, 64 x 64 per wave
+  constexpr int STAGE_BYTES = (BM + BN) * TILE_ROW_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nwg = pr.tiles_m * pr.tiles_n;
+  int tile;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  // tile_m fastest: the (few) query tiles that share a gallery panel run back to back on one XCD
+  const int tm = tile % pr.tiles_m, tn = tile / pr.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  constexpr int AG = BM / 8 / 4, BG = BN / 8 / 4;
+  const uint8_t* a_src[AG];
+  const uint8_t* w_src[BG];
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int tr = (wave + 4 * i) * 8 + (lane >> 3);
+    const int r = min(m0 + tr, pr.M - 1);
+    a_src[i] = pr.A + (long long)r * pr.lda + (((lane & 7) ^ ((tr >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < BG; ++i) {
+    const int tr = (wave + 4 * i) * 8 + (lane >> 3);
+    const int r = min(n0 + tr, pr.N - 1);
+    w_src[i] = pr.W + (long long)r * pr.ldw + (((lane & 7) ^ ((tr >> 1) & 7)) << 4);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nk = pr.K >> 7;                       // 128 K bytes per step
+  auto stage = [&](int buf, int ks) {
+    char* ta = smem + buf * STAGE_BYTES;
+    char* tw = ta + BM * TILE_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < AG; ++i) glds16(a_src[i] + ks * 128, ta + (wave + 4 * i) * 8 * TILE_ROW_BYTES);
+#pragma unroll
+    for (int i = 0; i < BG; ++i) glds16(w_src[i] + ks * 128, tw + (wave + 4 * i) * 8 * TILE_ROW_BYTES);
+  };
+  stage(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+    const char* ta = smem + (ks & 1) * STAGE_BYTES;
+    const char* tw = ta + BM * TILE_ROW_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {              // two 64-deep MFMA steps per 128-byte row
+      const int ch = 4 * s2 + 2 * (lane >> 5);
+      i32x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + (lane & 31);
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(ta + tile_off(row, ch));
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(ta + tile_off(row, ch + 1));
+        af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + (lane & 31);
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(tw + tile_off(row, ch));
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(tw + tile_off(row, ch + 1));
+        bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bfr[j], acc[i][j], 0, 0, 0, 127, 0, 127);
+    }
+  }
+  // C/D map of 32x32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      const float ws = n < pr.N ? pr.w_scale[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < pr.M && n < pr.N) pr.C[(long long)m * pr.ldc + n] = acc[i][j][e] * pr.a_scale[m] * ws;
+      }
+    }
+}
+
+int launch_gemm_nt_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
+                       float* C, int ldc, int M, int N, int K, hipStream_t stream) {
+  if (!A || !W || !C || !a_scale || !w_scale || M <= 0 || N <= 0 || K <= 0) return VPR_ERR_INVALID_ARG;
+  if ((K % 128) || lda < K || ldw < K || ldc < N || (lda % 16) || (ldw % 16)) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) return VPR_ERR_UNSUPPORTED;
+  GemmFp8Problem g{A, lda, W, ldw, a_scale, w_scale, C, ldc, M, N, K, (M + 127) / 128, (N + 127) / 128};
+  constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
+  VPR_TRY_LAUNCH(launch_kernel(gemm_nt_fp8_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g));
+  return VPR_OK;
+}
+
 static int gemm_check(const GemmProblem& g) {
   if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return VPR_ERR_INVALID_ARG;
   if (g.K % 64 != 0 || g.lda < g.K || g.ldw < g.K || g.ldc < g.N) return VPR_ERR_UNSUPPORTED;

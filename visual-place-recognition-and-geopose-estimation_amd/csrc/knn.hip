@@ -757,6 +757,9 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // 192 x 33k 406 / 300, 256 x 25k 477 / 185, 512 x 12.5k 702 / 151 (scripts/knn_b_sweep.py).
   const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the crossover
   const int gemm_min_b = genv ? atoi(genv) : 65;
+  if (o.fp8 && B >= gemm_min_b)      // block-scaled fp8 MFMA GEMM (twice the bf16 rate), scales in its epilogue
+    return launch_gemm_nt_fp8(static_cast<const uint8_t*>(o.q), D, o.q_scale, static_cast<const uint8_t*>(o.g), D,
+                              o.g_scale, S, p.ldS, B, N, D, stream);
   if (!o.fp8 && B >= gemm_min_b)
     return launch_gemm_nt(static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr,
                           0, S, p.ldS, 0, B, N, D, stream);

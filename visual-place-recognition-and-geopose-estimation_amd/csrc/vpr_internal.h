@@ -21,6 +21,9 @@ struct GemmProblem {
 };
 constexpr int GEMM_MAX_GROUP = 3;
 int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
+// gemm_nt.hip: fp8 e4m3 operands with per-row scales, f32 out (kNN score tile for > 64 queries); K % 128 == 0
+int launch_gemm_nt_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
+                       float* C, int ldc, int M, int N, int K, hipStream_t stream);
 int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
 // skinny.hip: a few rows x [N, K]^T; mode 0 bias, 1 bias+tanh-GELU, 2 accumulate into out, 3 bias+ReLU
 int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias, int bias_is_bf16,
