@@ -127,13 +127,16 @@ __global__ __launch_bounds__(256, WGPC) void knn_scores_kernel(
           const bf16x8 b0 = lds_frag(tg, 16 * nb + (lane & 15), (lane >> 4));
           const bf16x8 b1 = lds_frag(tg, 16 * nb + (lane & 15), 4 + (lane >> 4));
           if constexpr (FP8) {
-            typedef __attribute__((ext_vector_type(2))) long l64x2;
-            const l64x2 A0 = __builtin_bit_cast(l64x2, a0), A1 = __builtin_bit_cast(l64x2, a1);
-            const l64x2 B0 = __builtin_bit_cast(l64x2, b0), B1 = __builtin_bit_cast(l64x2, b1);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A0[0], B0[0], acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A0[1], B0[1], acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A1[0], B1[0], acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A1[1], B1[1], acc[nb], 0, 0, 0);
+            // one block-scaled MFMA (unit E8M0 scales) over the whole 128-byte K-step: a lane's 32 operand bytes
+            // are its two 16-byte chunks (same lane -> K assignment for both operands); twice the rate of the
+            // four v_mfma_f32_16x16x32_fp8_fp8 this replaces
+            typedef __attribute__((ext_vector_type(8))) int i32x8;
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const i32x4 A0 = __builtin_bit_cast(i32x4, a0), A1 = __builtin_bit_cast(i32x4, a1);
+            const i32x4 B0 = __builtin_bit_cast(i32x4, b0), B1 = __builtin_bit_cast(i32x4, b1);
+            const i32x8 A = {A0[0], A0[1], A0[2], A0[3], A1[0], A1[1], A1[2], A1[3]};
+            const i32x8 Bv = {B0[0], B0[1], B0[2], B0[3], B1[0], B1[1], B1[2], B1[3]};
+            acc[nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, Bv, acc[nb], 0, 0, 0, 127, 0, 127);
           } else {
             acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
             acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[nb], 0, 0, 0);
