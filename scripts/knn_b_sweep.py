@@ -23,8 +23,9 @@ for (B, N) in [(128, 50000), (192, 33333), (256, 25000), (512, 12500)]:
     q, gal = rows(B), rows(N)
     ws = ops.knn_workspace(B, N, D, 10, dev)
     line = f"B={B:4d} N={N:6d}:"
-    for thr in (100000, 1):
+    for thr, stages in ((100000, "2"), (1, "2"), (1, "3")):
         os.environ["VPR_KNN_GEMM_MIN_B"] = str(thr)
+        os.environ["VPR_GEMM_NT_STAGES"] = stages
         t = timeit(lambda: ops.knn_scores(q, gal, ws))
-        line += f"  {'stream' if thr > 1 else 'gemm  '} {t:7.1f} us"
+        line += f"  {'stream' if thr > 1 else 'gemm/' + stages + '-stage'} {t:7.1f} us"
     print(line, flush=True)

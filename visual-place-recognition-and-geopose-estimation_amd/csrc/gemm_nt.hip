@@ -145,10 +145,10 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmProblem& pr, int orig, ch
     }
 }
 
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmProblem pr) {
+template <int BN, int WM, int WN, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES > 2 ? 1 : 2) void gemm_nt_kernel(GemmProblem pr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_tile<BN, WM, WN>(pr, blockIdx.x, smem);
+  gemm_nt_tile<BN, WM, WN, STAGES>(pr, blockIdx.x, smem);
 }
 
 // Several independent small GEMMs in one launch (the SALAD layer-2 / token-MLP GEMMs are a few
@@ -304,6 +304,21 @@ int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_gro
   g.tiles_m = (M + 127) / 128;
   if (N > 64) {
     g.tiles_n = (N + 127) / 128;
+    // A/B switch: 3 = three-deep ring (96 KB: one workgroup per CU).  Measured on the kNN score tile, 2 vs 3
+    // stages: 128 x 50k 217 / 291 us, 512 x 12.5k 141 / 205 us — two workgroups per CU beat the deeper ring.
+    const char* senv = getenv("VPR_GEMM_NT_STAGES");
+    if (senv && atoi(senv) == 3) {
+      constexpr size_t lds3 = 3 * (128 + 128) * TILE_ROW_BYTES;
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<128, 2, 2, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+          return VPR_ERR_LAUNCH;
+        attr = true;
+      }
+      VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2, 3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds3, stream, g));
+      return VPR_OK;
+    }
     constexpr size_t lds = 2 * (128 + 128) * TILE_ROW_BYTES;
     VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, stream, g));
   } else {
