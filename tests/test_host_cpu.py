@@ -74,7 +74,10 @@ def test_shard_bounds_cover_gallery():
 
 class OracleEngine:
     """Test double for the HIP engine: same contract, CPU oracle arithmetic."""
-    def local_topk(self, q, gallery, k, index_base):
+    def local_topk(self, q, gallery, k, index_base, scales=None):
+        if gallery.dtype == torch.uint8:                       # e4m3 shard: quantise the queries like HipEngine does
+            q8, qs = oknn.quantize_fp8_rows(q.float())
+            return oknn.knn_topk_fp8(q8, qs, gallery, scales, k, index_base)
         return oknn.knn_topk(q, gallery, k, index_base)
 
     def merge(self, vals, idxs):
@@ -242,3 +245,28 @@ def test_finetune_head_on_cached_descriptors(tmp_path):
     assert torch.equal(re.regressor[0].weight, model.regressor[0].weight)
     ck = torch.load(tmp_path / "checkpoint_2_.pth", weights_only=True)
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+
+
+def test_sharded_gallery_fp8_shards_two_way_equals_unsharded():
+    """Host logic for e4m3 shards (rows uint8 + per-row scales): two shards searched separately and merged give
+    the unsharded answer; shape / argument validation."""
+    from vpr_amd.retrieval import ShardedGallery, shard_bounds
+    g = torch.Generator().manual_seed(5)
+    N, B, D, k = 600, 7, 256, 4
+    gal = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(torch.bfloat16)
+    g8, gs = oknn.quantize_fp8_rows(gal)
+    eng = OracleEngine()
+    whole = ShardedGallery(g8, N, 0, 1, engine=eng, scales=gs)
+    v, i = whole.search(q, k)
+    parts_v, parts_i = [], []
+    for r in range(2):
+        lo, hi = shard_bounds(N, r, 2)
+        pv, pi = eng.local_topk(q, g8[lo:hi], k, lo, gs[lo:hi])
+        parts_v.append(pv); parts_i.append(pi)
+    mv, mi = eng.merge(torch.stack(parts_v), torch.stack(parts_i))
+    assert torch.equal(mi, i) and torch.equal(mv, v)
+    with pytest.raises(ValueError):
+        ShardedGallery(g8, N, 0, 1, engine=eng)                       # uint8 rows need scales
+    with pytest.raises(ValueError):
+        ShardedGallery(gal.to(torch.bfloat16), N, 0, 1, engine=eng, scales=gs)   # bf16 rows must not carry scales
