@@ -143,7 +143,7 @@ __device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&p
   return mxn;
 }
 
-template <int NW, bool PIPE>
+template <int NW, bool PIPE, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int Tp, long long tail_row0, int H,
     float scale_log2e) {
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
   }
   __syncthreads();
 
+  if (ABL == 3) return;            // ablation: staging only
   const int qcol = lane & 15, g = lane >> 4;
   const int ntile = (T + 15) >> 4;
 
@@ -226,8 +227,24 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
       const int qt = wave + NW * j;
       if (qt < ntile) {
         attn_qk_all(cx, qf[j], sc);
+        if (ABL == 4) {                  // ablation: QK^T only (scores summed into one store so nothing is dead)
+          float a = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < AT_KP / 16; ++kb) a += sc[kb][0] + sc[kb][1] + sc[kb][2] + sc[kb][3];
+          if (qt * 16 + cx.qcol < T) cx.out[attn_row(cx, qt * 16 + cx.qcol) * cx.out_stride + 4 * cx.g] = f32_to_bf16_bits(a);
+          continue;
+        }
         const float mx = attn_rowmax(sc);
         const float ppad = attn_phase1(cx, sc, mx, pb, false, qf[j]);
+        if (ABL == 2) {                  // ablation: no PV (probabilities summed into one store)
+          float a = ppad;
+#pragma unroll
+          for (int t = 0; t < AT_KP / 32; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += (float)pb[t][e];
+          if (qt * 16 + cx.qcol < T) cx.out[attn_row(cx, qt * 16 + cx.qcol) * cx.out_stride + 4 * cx.g] = f32_to_bf16_bits(a);
+          continue;
+        }
         attn_phase2(cx, pb, ppad, qt, false, sc);
       }
     }
@@ -261,6 +278,18 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
     VPR_TRY_LAUNCH(launch_kernel(attention_kernel<NW, PIPE>, dim3((unsigned)(B * H)), dim3(NW * 64), AT_LDS, st, \
                                  qkv, out, T, Tp, tail_row0, H, c));                                                    \
   } while (0)
+#define VPR_ATTN_ABL(A)                                                                                   \
+  do {                                                                                                   \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<8, false, A>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_LDS) != hipSuccess)      \
+      return VPR_ERR_LAUNCH;                                                                             \
+    VPR_TRY_LAUNCH(launch_kernel(attention_kernel<8, false, A>, dim3((unsigned)(B * H)), dim3(512), AT_LDS, st, \
+                                 qkv, out, T, Tp, tail_row0, H, c));                                     \
+  } while (0)
+  // Ablations (variants 12-14, timing only): K/V + Q staging alone 11.4 us (101 MB of qkv at ~9 TB/s out of the
+  // Infinity Cache), + QK^T 24.2, + softmax 32.9, full kernel 37.5 us: the phases add up, i.e. the two workgroups of a
+  // CU run in lockstep and staging does not overlap compute.  A persistent variant would need both K/V sets in LDS
+  // (144 KB: one workgroup, two waves per SIMD).
   // Measured at B=64, T=257, H=16 (PyTorch SDPA: 94-99 us): 8 waves, one tile at a time, 128 VGPRs,
   // 4 waves/SIMD: 37 us (default); 4 waves: 44 us; 4 waves software-pipelined across tiles
   // (208 VGPRs, 2 waves/SIMD): 45 us — occupancy beats intra-wave overlap here.
@@ -268,9 +297,13 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
     case 1: VPR_ATTN_LAUNCH(4, false); break;
     case 2: VPR_ATTN_LAUNCH(4, true); break;
     case 3: VPR_ATTN_LAUNCH(6, false); break;
+    case 12: VPR_ATTN_ABL(2); break;   // ablations (timing only, wrong results): no PV
+    case 13: VPR_ATTN_ABL(3); break;   // staging only
+    case 14: VPR_ATTN_ABL(4); break;   // staging + QK^T
     default: VPR_ATTN_LAUNCH(8, false); break;
   }
 #undef VPR_ATTN_LAUNCH
+#undef VPR_ATTN_ABL
   return VPR_OK;
 }
 
