@@ -289,7 +289,9 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
   // Ablations (variants 12-14, timing only): K/V + Q staging alone 11.4 us (101 MB of qkv at ~9 TB/s out of the
   // Infinity Cache), + QK^T 24.2, + softmax 32.9, full kernel 37.5 us: the phases add up, i.e. the two workgroups of a
   // CU run in lockstep and staging does not overlap compute.  A persistent variant would need both K/V sets in LDS
-  // (144 KB: one workgroup, two waves per SIMD).
+  // (144 KB: one workgroup, two waves per SIMD).  Tried: K and V staged by LDS-DMA with the first tile's QK^T + softmax
+  // running before V has landed (padded keys masked in the scores instead of zero-filled rows): correct, but 45.7 us —
+  // the scattered 128-byte DMA pieces, the mask and 6 spilled registers cost more than the overlap returns.
   // Measured at B=64, T=257, H=16 (PyTorch SDPA: 94-99 us): 8 waves, one tile at a time, 128 VGPRs,
   // 4 waves/SIMD: 37 us (default); 4 waves: 44 us; 4 waves software-pipelined across tiles
   // (208 VGPRs, 2 waves/SIMD): 45 us — occupancy beats intra-wave overlap here.
