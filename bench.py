@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--cls-before-gemm", action="store_true", help="cls-row launches before the library GEMM that shares their weights (A/B)")
     ap.add_argument("--knn-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="gallery / query storage for the kNN stage: bf16 (headline) or e4m3 + per-row scale (BASELINE config 5 flavour)")
+    ap.add_argument("--no-side-chain", action="store_true", help="cls-row kernels in the main stream instead of a side stream forked / joined once per block (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     a = ap.parse_args()
 
@@ -135,6 +136,7 @@ def main():
     ext.backbone.hip_split = not a.no_split
     ext.backbone.fuse_ln_cls = a.fuse_ln_cls
     ext.backbone.cls_after_gemm = not a.cls_before_gemm
+    ext.backbone.cls_side_chain = not a.no_side_chain
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))

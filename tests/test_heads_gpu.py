@@ -190,7 +190,7 @@ def test_bias_layernorm_cls_linear(dev, gelu, C, N, n_cls, M):
     assert err < max(2.0 * err_unfused, 8e-3 * max(1.0, ref.abs().max().item())), (err, err_unfused)
 
 
-@pytest.mark.parametrize("mode", ["split", "split_unfused", "resid_gemm", "add_ln"])
+@pytest.mark.parametrize("mode", ["split_side", "split", "split_unfused", "resid_gemm", "add_ln"])
 def test_backbone_hip_path_matches_block_loop(dev, mode):
     """The HIP backbone paths (split row layout with patchify embedding; cls-first layout with the
     residual add inside the proj/fc2 GEMMs + deferred biases; cls-first with fused add+LN) give the
@@ -199,6 +199,7 @@ def test_backbone_hip_path_matches_block_loop(dev, mode):
     torch.manual_seed(0)
     m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
     m.hip_split = mode.startswith("split")
+    m.cls_side_chain = mode == "split_side"
     m.fuse_ln_cls = mode == "split"
     m.residual_in_gemm = mode != "add_ln"
     for b in m.blocks:
@@ -249,6 +250,22 @@ def test_patch_embed_hip_matches_conv(dev):
         ref = torch.cat([m32.cls_token.expand(2, -1, -1), t], dim=1) + m32.pos_embed
     tol = 0.02 * max(1.0, ref.abs().max().item())
     assert (body - ref[:, 1:]).abs().max().item() < tol and (cls - ref[:, 0]).abs().max().item() < tol
+
+
+def test_cls_side_chain_is_bit_identical_to_in_stream_path(dev):
+    """The cls rows on their own stream (one fork after each attention, one join before the next): same kernels
+    on the same data, so the tokens must equal the single-stream path bit for bit — run twice to catch a race."""
+    from vpr_amd.backbone import DinoV2
+    torch.manual_seed(3)
+    m = DinoV2("vit_small").to(dev).to(torch.bfloat16).eval()
+    m.fold_layerscale()
+    x = torch.randn(5, 3, 224, 224, device=dev, dtype=torch.bfloat16)
+    m.cls_side_chain = False
+    ref = m(x, split=True)
+    m.cls_side_chain = True
+    for _ in range(3):
+        got = m(x, split=True)
+        assert torch.equal(got.patch, ref.patch) and torch.equal(got.cls, ref.cls)
 
 
 def test_split_tokens_roundtrip_and_salad_split(dev):

@@ -165,6 +165,70 @@ class DinoV2(nn.Module):
             self._embed_w, self._embed_off, self._embed_key = w, off, key
         return self._embed_w, self._embed_off
 
+    cls_side_chain = True
+
+    def _blocks_side_chain(self, x: torch.Tensor, h: torch.Tensor, cum: torch.Tensor, B: int, n: int, C: int) -> "SplitTokens":
+        """The 24 blocks with the cls rows on their own stream.  Between two attentions the B cls rows need six
+        small kernels (proj, LayerNorm, fc1, fc2, LayerNorm, next qkv: ~40 us) that depend on nothing but the cls
+        rows of the attention output; in-stream they cost 0.8 ms per step, almost all of it launch latency.  Here
+        the side stream is forked right after each attention and joined right before the next one, ~375 us of
+        patch-row GEMMs later, so the join never waits (an earlier attempt forked and joined around every single
+        cls-row launch and lost 0.6 ms to cross-queue waits).  The main stream touches only patch rows
+        (x[:Mp], LayerNorm on the patch slice), the side stream only cls rows: no shared writes.
+        Lifetimes: `att` (read by the side stream) and `qkv_next` (written by it) stay referenced until after
+        the join; side-stream temporaries come from that stream's allocator pool."""
+        from . import ops
+        Mp, M = B * n, B * n + B
+        dev, bf = x.device, torch.bfloat16
+        blocks = self.blocks
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != dev:
+            # high priority: the cls-row workgroups take the first CU slots a retiring GEMM workgroup frees (the
+            # library GEMMs fill every CU, so at equal priority the small kernels sit in the queue: 40-95 us each)
+            import os
+            prio = int(os.environ.get("VPR_SIDE_PRIORITY", "-1"))
+            side = self._side = torch.cuda.Stream(device=dev, priority=prio)
+        C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
+        xp, xc = x[:Mp], x[Mp:]
+        hp = h[:Mp]
+        qkv = torch.empty((M, C3), dtype=bf, device=dev)
+        torch.addmm(blocks[0].qkv.bias, hp, blocks[0].qkv.weight.t(), out=qkv[:Mp])
+        ops.skinny_linear_bf16(h[Mp:], blocks[0].qkv.weight, blocks[0].qkv.bias, qkv[Mp:], 0)
+        cls_out = None
+        for i, blk in enumerate(blocks):
+            last = i + 1 == len(blocks)
+            nb = blocks[i + 1] if not last else None
+            nxt = nb.norm1 if not last else self.norm
+            att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
+            qkv_next = torch.empty((M, C3), dtype=bf, device=dev) if not last else None
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, xc, 2)
+                hc = ops.bias_layernorm_bf16(xc, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+                hhc = torch.empty((B, C4), dtype=bf, device=dev)
+                ops.skinny_linear_bf16(hc, blk.fc1.weight, blk.fc1.bias, hhc, 1)
+                ops.skinny_linear_bf16(hhc, blk.fc2.weight, None, xc, 2)
+                hc2 = ops.bias_layernorm_bf16(xc, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
+                if not last:
+                    ops.skinny_linear_bf16(hc2, nb.qkv.weight, nb.qkv.bias, qkv_next[Mp:], 0)
+                else:
+                    cls_out = hc2
+                join = torch.cuda.Event()
+                join.record(side)
+            xp.addmm_(att[:Mp], blk.proj.weight.t())
+            hp = ops.bias_layernorm_bf16(xp, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            hh = torch._addmm_activation(blk.fc1.bias, hp, blk.fc1.weight.t(), use_gelu=True)
+            xp.addmm_(hh, blk.fc2.weight.t())
+            hp = ops.bias_layernorm_bf16(xp, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
+            if not last:
+                torch.addmm(nb.qkv.bias, hp, nb.qkv.weight.t(), out=qkv_next[:Mp])
+            main.wait_event(join)          # the side chain finished ~0.3 ms ago: satisfied on arrival
+            qkv = qkv_next                 # (att stayed referenced up to here)
+        return SplitTokens(hp.view(B, n, C), cls_out)
+
     def _raw_tokens(self, M: int, Mp: int, C: int, dev: torch.device) -> torch.Tensor:
         buf = getattr(self, "_raw_buf", None)
         if buf is None or buf.shape != (M, C) or buf.device != dev:
@@ -199,6 +263,9 @@ class DinoV2(nn.Module):
         n0 = blocks[0].norm1
         x, h = ops.add_layernorm_bf16(raw, off, n0.weight, n0.bias, n0.eps)
         cum = self._cumulative_bias(dev)
+
+        if self.cls_side_chain:
+            return self._blocks_side_chain(x, h, cum, B, n, C)
 
         # patch rows: library GEMMs; cls rows: vpr_skinny_linear_bf16 (a library GEMM spends 9-14 us on 64 rows).
         # cls_after_gemm: each cls-row launch comes right AFTER the library GEMM that used the same weight
