@@ -50,6 +50,15 @@ def test_bench_fp8_gallery(dev):
     assert d["value"] > 0 and d["recall_at_1"] == 1.0
 
 
+def test_bench_two_batches_in_flight(dev):
+    """--in-flight 2: consecutive steps on two streams (per-stream workspaces, per-stream side chain)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--in-flight", "2",
+                        "--no-cpu-baseline"] + SMALL + ["--steps", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _json_line(p.stdout)
+    assert d["config"]["batches_in_flight"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["recall_at_1"] == 1.0
+
+
 def test_bench_two_ranks_gloo_rehearsal(dev):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

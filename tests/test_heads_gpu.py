@@ -268,6 +268,27 @@ def test_cls_side_chain_is_bit_identical_to_in_stream_path(dev):
         assert torch.equal(got.patch, ref.patch) and torch.equal(got.cls, ref.cls)
 
 
+def test_two_streams_drive_the_extractor_concurrently(dev):
+    """Two batches in flight on two streams (each with its own workspaces, raw-token buffer and cls side
+    stream) give the descriptors of the sequential run, bit for bit."""
+    from vpr_amd.modules import DinoV2Salad
+    torch.manual_seed(4)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    xs = [torch.randn(6, 3, 224, 224, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+    ref = [ext(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(3):
+        outs = [None, None]
+        for j, (x, s) in enumerate(zip(xs, (s1, s2))):
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                outs[j] = ext(x)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+
+
 def test_split_tokens_roundtrip_and_salad_split(dev):
     """forward(split=True).joined() == forward(); SALAD on the pair == SALAD on the joined tensor (bit-exact:
     same kernels, only the row addressing differs)."""

@@ -182,13 +182,15 @@ class DinoV2(nn.Module):
         dev, bf = x.device, torch.bfloat16
         blocks = self.blocks
         main = torch.cuda.current_stream(dev)
-        side = getattr(self, "_side", None)
-        if side is None or side.device != dev:
+        sides = self.__dict__.setdefault("_sides", {})      # one side stream per (device, main stream)
+        skey = (str(dev), main.cuda_stream)
+        side = sides.get(skey)
+        if side is None:
             # high priority: the cls-row workgroups take the first CU slots a retiring GEMM workgroup frees (the
             # library GEMMs fill every CU, so at equal priority the small kernels sit in the queue: 40-95 us each)
             import os
             prio = int(os.environ.get("VPR_SIDE_PRIORITY", "-1"))
-            side = self._side = torch.cuda.Stream(device=dev, priority=prio)
+            side = sides[skey] = torch.cuda.Stream(device=dev, priority=prio)
         C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
         xp, xc = x[:Mp], x[Mp:]
         hp = h[:Mp]
@@ -230,10 +232,13 @@ class DinoV2(nn.Module):
         return SplitTokens(hp.view(B, n, C), cls_out)
 
     def _raw_tokens(self, M: int, Mp: int, C: int, dev: torch.device) -> torch.Tensor:
-        buf = getattr(self, "_raw_buf", None)
-        if buf is None or buf.shape != (M, C) or buf.device != dev:
-            buf = torch.zeros((M, C), dtype=torch.bfloat16, device=dev)
-            self._raw_buf = buf
+        bufs = self.__dict__.setdefault("_raw_bufs", {})     # per (device, stream, shape): two streams never share it
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, M, C)
+        buf = bufs.get(key)
+        if buf is None:
+            if len(bufs) > 8:
+                bufs.clear()
+            buf = bufs[key] = torch.zeros((M, C), dtype=torch.bfloat16, device=dev)
         return buf
 
     def _forward_hip_split(self, img: torch.Tensor) -> "SplitTokens":

@@ -37,8 +37,10 @@ def _need(t: torch.Tensor, dtype: torch.dtype, name: str, ndim: Optional[int] = 
 
 
 def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
-    """Cached byte buffer per (device, name); grows, never shrinks.  One stream per device assumed."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), name)
+    """Cached byte buffer per (device, stream, name); grows, never shrinks.  Keyed by the current stream so that
+    two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream, name)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
