@@ -67,6 +67,8 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
     model = DINOv2RegressionModel(base_model).to(dev)
     load_reference_checkpoint(model, checkpoint_path)            # checkpoint['model_state_dict'] or a bare state dict
     model.eval()
+    if hasattr(getattr(base_model, "backbone", None), "fold_layerscale"):
+        base_model.backbone.fold_layerscale()                    # inference only: LayerScale into proj / fc2, enables the HIP backbone path
     base_model.aggregator.pack()
     scaler = scaler or postproc.LatLonScaler.campus()
     prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)   # validation.py:18-22
