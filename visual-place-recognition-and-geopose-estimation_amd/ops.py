@@ -17,8 +17,16 @@ from . import _lib
 _WORKSPACES = {}
 
 
+def _raw_stream(device_index: int = -1) -> int:
+    """Current HIP stream handle of a device (torch.cuda.current_stream() costs ~8 us of Python per call; this is
+    the C entry point underneath it, ~0.3 us — there are ~300 launches per pipeline step)."""
+    if device_index < 0:
+        device_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
 def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
@@ -39,8 +47,8 @@ def _need(t: torch.Tensor, dtype: torch.dtype, name: str, ndim: Optional[int] = 
 def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
     """Cached byte buffer per (device, stream, name); grows, never shrinks.  Keyed by the current stream so that
     two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream, name)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx), name)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
