@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# Kernel arguments in device memory instead of host-coherent memory: ~1 us less dispatch latency per kernel on this
+# runtime, ~300 kernels per step: 11.74 -> 11.41 ms per step (same box, twice).  Read by the HIP runtime when it
+# initialises, so it has to be in the environment before the first HIP call; an explicit setting wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn

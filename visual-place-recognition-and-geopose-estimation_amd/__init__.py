@@ -10,5 +10,11 @@ imported from this package.
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# ~300 kernel launches per pipeline step: kernel arguments in device memory save ~1 us of dispatch latency each
+# (bench.py: 11.74 -> 11.41 ms per step).  Takes effect only if the HIP runtime has not initialised yet.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 from . import _lib  # noqa: F401  (ctypes binding; loads lazily)
 from .build import build_library, library_path  # noqa: F401
