@@ -243,7 +243,7 @@ int vpr_bias_layernorm_bf16(const uint16_t* x, const float* pre_bias, const void
 
 /* Linear layer on a few rows (backbone helper: the cls-token rows of the split row layout):
  * mode 0: out = in W^T + bias; mode 1: out = gelu_tanh(in W^T + bias); mode 2: out += in W^T (bf16 read-modify-write,
- * bias unused).  in [M, K] bf16 (ldi), W [N, K] bf16 (ldw), bias [N] bf16 or f32, out [M, N] bf16 (ldo).
+ * bias unused); mode 3: relu(in W^T + bias); mode 4: exact (erf) GELU, the nn.GELU() of DINOv2's Mlp.  in [M, K] bf16 (ldi), W [N, K] bf16 (ldw), bias [N] bf16 or f32, out [M, N] bf16 (ldo).
  * K % 32 == 0, ldi/ldw % 8 == 0; f32 accumulation in a fixed order (deterministic). */
 int vpr_skinny_linear_bf16(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias,
                            int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K, void* stream);

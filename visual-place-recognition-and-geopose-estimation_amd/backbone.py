@@ -77,7 +77,10 @@ class Block(nn.Module):
     @torch.no_grad()
     def fold_layerscale(self) -> None:
         """ls * (W a + b) == (diag(ls) W) a + ls * b: rewrite proj / fc2 once, then skip the two
-        elementwise multiplies in forward.  Changes rounding only (bf16 weights are re-rounded)."""
+        elementwise multiplies in forward.  Changes rounding only (bf16 weights are re-rounded).
+        ls1 / ls2 become ones, so the parameters always describe the same function whichever way they
+        are read: a state dict saved from a folded model loads into a fresh one correctly (ls = 1 there),
+        and `folded` is only the licence to skip a multiply by one."""
         if self.folded:
             return
         for lin, ls in ((self.proj, self.ls1), (self.fc2, self.ls2)):
@@ -85,7 +88,14 @@ class Block(nn.Module):
             b = (ls.float() * lin.bias.float()).to(lin.bias.dtype)
             lin.weight.copy_(w)
             lin.bias.copy_(b)
+            ls.fill_(1.0)
         self.folded = True
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # Any load may bring unfolded weights and real LayerScale values back: the fold licence ends
+        # here (the loaded ls1 / ls2 are applied again until fold_layerscale() is called anew).
+        super()._load_from_state_dict(*args, **kwargs)
+        self.folded = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, T, C = x.shape
@@ -112,6 +122,26 @@ class DinoV2(nn.Module):
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
         nn.init.normal_(self.cls_token, std=1e-6)
+        self._register_load_state_dict_pre_hook(self._adopt_foreign_keys)
+
+    # None: 0.1 for facebookresearch/dinov2 (hub) key layouts, 0 for Hugging Face ones (checkpoint.py)
+    pos_embed_interpolate_offset: Optional[float] = None
+
+    def _adopt_foreign_keys(self, state_dict, prefix, *unused) -> None:
+        """load_state_dict pre-hook (runs for a load through ANY ancestor, e.g. the strict load of
+        dinov2salad_validation.py:69 on DINOv2RegressionModel): rewrites, in place, the keys under this
+        module's prefix from the hub / serizba-salad (`model.` level, attn.qkv, ls1.gamma, patch_embed.proj,
+        mask_token, 37x37 pos_embed) or Hugging Face layout into this class's names — checkpoint.py."""
+        from .checkpoint import convert_state_dict
+        mine = [k for k in state_dict if k.startswith(prefix)]
+        if not mine:
+            return
+        sub = {}
+        for k in mine:
+            rest = k[len(prefix):]
+            sub[rest[6:] if rest.startswith("model.") else rest] = state_dict.pop(k)
+        for k, v in convert_state_dict(sub, self.num_patches, self.pos_embed_interpolate_offset).items():
+            state_dict[prefix + k] = v
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, split: bool = False):
@@ -129,6 +159,26 @@ class DinoV2(nn.Module):
                 x = blk(x)
             x = _ln(self.norm, x).contiguous()
         return SplitTokens(x[:, 1:].contiguous(), x[:, 0].contiguous()) if split else x
+
+    # GELU of the HIP path's fc1: "tanh" = inside the library GEMM's epilogue (hipBLASLt offers only the tanh
+    # form; |gelu_tanh - gelu_erf| <= 4.7e-4, below the bf16 spacing of every output above 0.12) or "erf" = the
+    # exact nn.GELU() DINOv2 uses, as a separate in-place pass (+45 us per block at B = 64).  The f32 / CPU block
+    # loop is always erf.  evaluate.py (reference checkpoints) selects "erf"; bench.py keeps the default.
+    gelu = "tanh"
+
+    def _fc1_gelu(self, blk: "Block", h: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.gelu == "tanh":
+            if out is None:
+                return torch._addmm_activation(blk.fc1.bias, h, blk.fc1.weight.t(), use_gelu=True)
+            return torch._addmm_activation(blk.fc1.bias, h, blk.fc1.weight.t(), use_gelu=True, out=out)
+        if self.gelu != "erf":
+            raise ValueError("DinoV2.gelu must be 'tanh' or 'erf'")
+        hh = torch.addmm(blk.fc1.bias, h, blk.fc1.weight.t()) if out is None else torch.addmm(blk.fc1.bias, h, blk.fc1.weight.t(), out=out)
+        return torch._C._nn.gelu_(hh)
+
+    @property
+    def _skinny_gelu_mode(self) -> int:
+        return 1 if self.gelu == "tanh" else 4
 
     hip_split = True
     cls_after_gemm = True
@@ -211,7 +261,7 @@ class DinoV2(nn.Module):
                 ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, xc, 2)
                 hc = ops.bias_layernorm_bf16(xc, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
                 hhc = torch.empty((B, C4), dtype=bf, device=dev)
-                ops.skinny_linear_bf16(hc, blk.fc1.weight, blk.fc1.bias, hhc, 1)
+                ops.skinny_linear_bf16(hc, blk.fc1.weight, blk.fc1.bias, hhc, self._skinny_gelu_mode)
                 ops.skinny_linear_bf16(hhc, blk.fc2.weight, None, xc, 2)
                 hc2 = ops.bias_layernorm_bf16(xc, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
                 if not last:
@@ -222,7 +272,7 @@ class DinoV2(nn.Module):
                 join.record(side)
             xp.addmm_(att[:Mp], blk.proj.weight.t())
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            hh = torch._addmm_activation(blk.fc1.bias, hp, blk.fc1.weight.t(), use_gelu=True)
+            hh = self._fc1_gelu(blk, hp)
             xp.addmm_(hh, blk.fc2.weight.t())
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
             if not last:
@@ -280,7 +330,7 @@ class DinoV2(nn.Module):
         # a side stream (cross-queue waits: 12.8 vs 12.2 ms/step).
         # fuse_ln_cls (option): the two cls-row linears that directly follow a LayerNorm (qkv, fc1) ride in
         # the LayerNorm's launch (vpr_bias_layernorm_cls_linear_bf16): 0.03-0.05 ms per step, default off.
-        fuse = self.fuse_ln_cls and C % 32 == 0
+        fuse = self.fuse_ln_cls and C % 32 == 0 and self.gelu == "tanh"     # the fused launch has the tanh form only
         after = self.cls_after_gemm
         rs = torch.empty((C // 16, B, 2), dtype=torch.float32, device=dev) if fuse else None   # stream-ordered reuse
         fc = self._cls_fused_consts(dev) if fuse else None
@@ -309,8 +359,8 @@ class DinoV2(nn.Module):
                                                        fc[2 * i + 1], hh[Mp:], gelu=True)
             else:
                 h = ops.bias_layernorm_bf16(x, cum[2 * i], n2.weight, n2.bias, n2.eps)
-            pair(lambda: torch._addmm_activation(blk.fc1.bias, h[:Mp], blk.fc1.weight.t(), use_gelu=True, out=hh[:Mp]),
-                 lambda: ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], 1), not fuse)
+            pair(lambda: self._fc1_gelu(blk, h[:Mp], out=hh[:Mp]),
+                 lambda: ops.skinny_linear_bf16(h[Mp:], blk.fc1.weight, blk.fc1.bias, hh[Mp:], self._skinny_gelu_mode), not fuse)
             pair(lambda: x[:Mp].addmm_(hh[:Mp], blk.fc2.weight.t()),
                  lambda: ops.skinny_linear_bf16(hh[Mp:], blk.fc2.weight, None, x[Mp:], 2,
                                                 cum[2 * i + 1] if fuse and not last else None, rs if not last else None))
@@ -364,7 +414,7 @@ class DinoV2(nn.Module):
             if self.residual_in_gemm:
                 x2.addmm_(a.view(B * T, C), blk.proj.weight.t())
                 h = ops.bias_layernorm_bf16(x2, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-                hh = torch._addmm_activation(blk.fc1.bias, h, blk.fc1.weight.t(), use_gelu=True)
+                hh = self._fc1_gelu(blk, h)
                 x2.addmm_(hh, blk.fc2.weight.t())
                 h = ops.bias_layernorm_bf16(x2, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps).view(B, T, C)
                 continue
@@ -374,7 +424,7 @@ class DinoV2(nn.Module):
                 # bias + GELU inside the fc1 GEMM epilogue (hipBLASLt's tanh form): removes a 270 MB
                 # elementwise pass per block.  Its deviation from erf-GELU (<= 3e-4) is below bf16
                 # resolution: against an f32 reference both forms measure the same max error (0.016).
-                hh = torch._addmm_activation(blk.fc1.bias, h.view(B * T, C), blk.fc1.weight.t(), use_gelu=True)
+                hh = self._fc1_gelu(blk, h.view(B * T, C))
                 y = blk.fc2(hh).view(B, T, C)
             else:
                 y = blk.fc2(F.gelu(blk.fc1(h)))

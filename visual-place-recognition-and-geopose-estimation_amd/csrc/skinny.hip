@@ -13,7 +13,7 @@
 
 namespace vpr {
 
-enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2, SK_BIAS_RELU = 3 };
+enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2, SK_BIAS_RELU = 3, SK_BIAS_GELU_ERF = 4 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2 u): the form hipBLASLt's epilogue uses
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
         if constexpr (sizeof(BiasT) == 2) b = bf16_bits_to_f32((uint16_t)bias[n + e]); else b = bias[n + e];
         v[e] += b;
         if (mode == SK_BIAS_GELU) v[e] = gelu_tanh(v[e]);
+        if (mode == SK_BIAS_GELU_ERF) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));   // nn.GELU() of DINOv2
         if (mode == SK_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
       }
       ob[e] = f32_to_bf16_bits(v[e]);
@@ -130,7 +131,7 @@ int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw
                          int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
                          const float* stats_bias, float* row_stats, void* stream) {
   if (row_stats != nullptr && (N % 16)) return VPR_ERR_UNSUPPORTED;
-  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 3) return VPR_ERR_INVALID_ARG;
+  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 4) return VPR_ERR_INVALID_ARG;
   if (mode != SK_ACCUMULATE && !bias) return VPR_ERR_INVALID_ARG;
   if (M == 0) return VPR_OK;
   if ((K % 32) || (ldi % 8) || (ldw % 8) || ldi < K || ldw < K || ldo < N) return VPR_ERR_UNSUPPORTED;

@@ -25,7 +25,7 @@ int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream
 int launch_gemm_nt_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
                        float* C, int ldc, int M, int N, int K, hipStream_t stream);
 int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
-// skinny.hip: a few rows x [N, K]^T; mode 0 bias, 1 bias+tanh-GELU, 2 accumulate into out, 3 bias+ReLU
+// skinny.hip: a few rows x [N, K]^T; mode 0 bias, 1 bias+tanh-GELU, 2 accumulate into out, 3 bias+ReLU, 4 bias+erf-GELU
 int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias, int bias_is_bf16,
                          int mode, uint16_t* out, int ldo, int M, int N, int K, const float* stats_bias,
                          float* row_stats, void* stream);

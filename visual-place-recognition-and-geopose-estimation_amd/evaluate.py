@@ -68,7 +68,8 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
     load_reference_checkpoint(model, checkpoint_path)            # checkpoint['model_state_dict'] or a bare state dict
     model.eval()
     if hasattr(getattr(base_model, "backbone", None), "fold_layerscale"):
-        base_model.backbone.fold_layerscale()                    # inference only: LayerScale into proj / fc2, enables the HIP backbone path
+        base_model.backbone.gelu = "erf"                         # the checkpoint was trained behind nn.GELU(): exact form, not the GEMM epilogue's tanh
+        base_model.backbone.fold_layerscale()                    # AFTER the load (a load un-folds): LayerScale into proj / fc2, enables the HIP backbone path
     base_model.aggregator.pack()
     scaler = scaler or postproc.LatLonScaler.campus()
     prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)   # validation.py:18-22
@@ -84,7 +85,7 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
     if verbose:
         print(all_preds.shape, all_targets.shape)
         print(f"final_loss: {final_loss}")
-        print("\\nSample Predictions (Original Scale):")
+        print("\nSample Predictions (Original Scale):")
         for i in range(min(5, len(all_preds))):
             (pl, po), (tl, to) = all_preds[i], all_targets[i]
             print(f"Prediction: (Lat: {pl:.6f}, Lon: {po:.6f}), True: (Lat: {tl:.6f}, Lon: {to:.6f}), "

@@ -201,7 +201,11 @@ class FusedGeoPoseHead(nn.Module):
 def load_reference_checkpoint(model: nn.Module, path: str) -> nn.Module:
     """Accepts both checkpoint forms the reference writes: {'model_state_dict': ...}
     (dinov2salad_finetuning.py:130-135, loaded at dinov2salad_validation.py:68-69) and bare
-    state dicts (swin_attempt_2.py:255, loaded at val_and_test_swin_2.py:231)."""
+    state dicts (swin_attempt_2.py:255, loaded at val_and_test_swin_2.py:231).  The load is strict,
+    as the reference's: the `feature_extractor.*` keys of the hub model (`backbone.model.blocks.N.attn.qkv`,
+    `ls1.gamma`, `patch_embed.proj`, `mask_token`, 37x37 `pos_embed`) are mapped onto DinoV2's by its
+    load hook (backbone.DinoV2._adopt_foreign_keys / checkpoint.py).  A load un-folds LayerScale: call
+    `backbone.fold_layerscale()` and `aggregator.pack()` afterwards (evaluate.py does)."""
     ckpt = torch.load(path, map_location="cpu", weights_only=True)
     state = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
     model.load_state_dict(state)

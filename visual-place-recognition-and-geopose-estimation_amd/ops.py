@@ -474,7 +474,7 @@ def skinny_linear_bf16(inp: torch.Tensor, weight: torch.Tensor, bias: Optional[t
                        mode: int = 0, stats_bias: Optional[torch.Tensor] = None,
                        row_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Linear layer on a few rows, written into `out` (a row slice of a larger buffer is fine):
-    mode 0 out = inp W^T + b; 1 gelu_tanh(inp W^T + b); 2 out += inp W^T.  With row_stats [N/16, M, 2] f32 it
+    mode 0 out = inp W^T + b; 1 gelu_tanh(inp W^T + b); 2 out += inp W^T; 3 relu; 4 erf-GELU.  With row_stats [N/16, M, 2] f32 it
     also leaves the per-16-column (mean, M2) of bf16(out) + stats_bias there (LayerNorm statistics partials)."""
     for t, name in ((inp, "inp"), (weight, "weight"), (out, "out")):
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
