@@ -227,3 +227,77 @@ def test_sharded_gallery_fp8_rows(dev):
     assert torch.equal(i[:, 0].cpu().long(), pos)
     with pytest.raises(ValueError):
         ShardedGallery(g8, N, 0, 1)                      # fp8 rows without scales
+
+
+# ------------------------------------------------------------- full-size shapes (BASELINE configs 3 and 5)
+def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
+    """Exact parity at sizes the CPU oracle cannot brute-force (N x 8448 up to 1M rows), in three steps:
+      1. gallery generated on the GPU slab by slab; queries = planted positives + noise (Recall@1 must be 1);
+      2. an INDEPENDENT approximate search (torch matmul in f32 per slab + torch.topk, k + `extra` per query) gives a
+         candidate set that contains the true top-k unless f32 GEMM error exceeds the gap to the (k+extra)-th score;
+      3. oracle/knn.py (exact f64 products, stable order) on the union U of those candidates and of the rows the HIP
+         path returned: every row of U is a real gallery row, U contains each query's true top-k, U is sorted by
+         global index (ties keep their order) -> the oracle's top-k over U IS the global answer, compared bit for bit
+         (indices and f32 values) with vpr_knn_topk / vpr_knn_topk_fp8."""
+    from vpr_amd import ops
+    D = 8448
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    rows = torch.empty((N, D), dtype=torch.uint8 if fp8 else torch.bfloat16, device=dev)
+    scales = torch.empty((N,), dtype=torch.float32, device=dev) if fp8 else None
+    pos = torch.randint(0, N, (B,), device=dev, generator=gen)
+    planted = torch.empty((B, D), dtype=torch.float32, device=dev)
+    for lo in range(0, N, slab):
+        n = min(slab, N - lo)
+        x = torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=gen), dim=1)
+        sel = (pos >= lo) & (pos < lo + n)
+        planted[sel] = x[pos[sel] - lo]
+        if fp8:
+            rows[lo:lo + n], scales[lo:lo + n] = ops.quantize_fp8_rows(x)
+        else:
+            rows[lo:lo + n] = x.to(torch.bfloat16)
+        del x
+    qf = torch.nn.functional.normalize(planted + 0.1 * torch.randn(B, D, device=dev, generator=gen), dim=1)
+    if fp8:
+        q, qs = ops.quantize_fp8_rows(qf)
+        v, i = ops.knn_topk_fp8(q, qs, rows, scales, k)
+        q_deq = q.view(torch.float8_e4m3fn).float() * qs[:, None]
+    else:
+        q = qf.to(torch.bfloat16)
+        v, i = ops.knn_topk(q, rows, k)
+        q_deq = q.float()
+    torch.cuda.synchronize()
+    assert torch.equal(i[:, 0].long(), pos), "planted positives are not top-1"
+    assert bool((v[:, :-1] >= v[:, 1:]).all())
+    # 2. independent approximate candidates
+    kk = k + extra
+    best_v = torch.full((B, kk), float("-inf"), device=dev)
+    best_i = torch.full((B, kk), -1, dtype=torch.int64, device=dev)
+    for lo in range(0, N, slab):
+        n = min(slab, N - lo)
+        g = rows[lo:lo + n].view(torch.float8_e4m3fn).float() * scales[lo:lo + n, None] if fp8 else rows[lo:lo + n].float()
+        sv, si = torch.topk(q_deq @ g.T, min(kk, n), dim=1)
+        cv, ci = torch.cat([best_v, sv], 1), torch.cat([best_i, si + lo], 1)
+        o = torch.topk(cv, kk, dim=1).indices
+        best_v, best_i = torch.gather(cv, 1, o), torch.gather(ci, 1, o)
+        del g
+    # 3. exact oracle on the union
+    U = torch.unique(torch.cat([best_i.flatten(), i.flatten().long()]))         # sorted ascending
+    U = U[U >= 0]
+    if fp8:
+        v_ref, li = oknn.knn_topk_fp8(q.cpu(), qs.cpu(), rows[U].cpu(), scales[U].cpu(), k)
+    else:
+        v_ref, li = oknn.knn_topk(q.cpu(), rows[U].cpu(), k)
+    i_ref = U.cpu()[li.long()].to(torch.int32)
+    assert torch.equal(i.cpu(), i_ref), "indices differ from the exact answer"
+    assert torch.equal(v.cpu(), v_ref), "values differ from the exact answer"
+
+
+@pytest.mark.parametrize("B,N,k,fp8", [
+    (64, 100_000, 10, False),     # config 3 on one GPU: bf16, one 196-row tile per workgroup
+    (64, 125_000, 10, True),      # config 5, one 8-way shard of the 1M gallery: multi-tile loop of knn_scores_kernel<fp8>
+    (512, 125_000, 10, True),     # config 5 on 8 GPUs: the all-gathered 512-query batch -> gemm_nt_fp8_kernel
+    (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard -> gemm_nt_kernel
+    (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU
+])
+def test_knn_full_size_exact(dev, B, N, k, fp8):
+    _full_size_check(dev, B, N, k, fp8, seed=B + N)

@@ -82,7 +82,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_lds_swizzle_is_conflict_free():
-    """Host re-derivation of vpr_common.cuh::tile_off for every ds_read_b128 lane group of both
+    """Host re-derivation of vpr_common.h::tile_off for every ds_read_b128 lane group of both
     MFMA operand maps (bank = (addr/4) % 64; a 16-lane group must hit 16 distinct 16-B slots)."""
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
               [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]

@@ -12,7 +12,7 @@
 // One workgroup (8 waves) per (image, head); each wave owns query tiles of 16 rows.
 // Input is the fused projection output qkv [B, T, 3, H, 64] (no q/k/v copies), output [B, T, H*64].
 #include <stdlib.h>
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -1,5 +1,5 @@
 // capi.hip — C-ABI odds and ends of libvpr_amd.so (see include/vpr_amd.h for the contract).
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

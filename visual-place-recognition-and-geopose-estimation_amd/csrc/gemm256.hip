@@ -18,7 +18,7 @@
 //     the LDS reads of the other on every SIMD.
 // Operand roles are swapped in the MFMA (A operand = W rows, B operand = A rows) so that a lane
 // ends up with 4 consecutive output columns: 8-byte bf16 / 16-byte f32 stores.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

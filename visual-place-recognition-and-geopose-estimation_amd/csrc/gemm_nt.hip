@@ -6,11 +6,11 @@
 //
 // Structure (cdna guide §5, "minimum 2-phase"): 128 x BN output tile per 256-thread workgroup,
 // BK = 64, both operand tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a 2-deep LDS
-// ring with the XOR swizzle of vpr_common.cuh on the source address, fragments read with
+// ring with the XOR swizzle of vpr_common.h on the source address, fragments read with
 // ds_read_b128, v_mfma_f32_32x32x16_bf16, one barrier per K-step.  Workgroup ids are remapped
 // so that the workgroups of one XCD (blockIdx % 8) own a contiguous run of tiles and re-use the
 // same A panel out of that XCD's L2.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {
@@ -102,8 +102,15 @@ __device__ __forceinline__ void gemm_nt_tile(const GemmProblem& pr, int orig, ch
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // ... then the barrier: tile ks has landed for every wave and every wave is done reading the buffer
-    // that the next issue overwrites (the one read at step ks-1).
-    __syncthreads();
+    // that the next issue overwrites (the one read at step ks-1).  A raw s_barrier: __syncthreads() would put
+    // `s_waitcnt vmcnt(0)` in front of it (checked in the ISA) and drain the tiles the counted wait left in flight.
+    if constexpr (STAGES > 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      __syncthreads();
+    }
     if (ks + STAGES - 1 < nk) stage((ks + STAGES - 1) % STAGES, ks + STAGES - 1);
     const char* ta = smem + (ks % STAGES) * STAGE_BYTES;
     const char* tw = ta + BM * TILE_ROW_BYTES;

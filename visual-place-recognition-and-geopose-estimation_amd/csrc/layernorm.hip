@@ -3,7 +3,7 @@
 // HBM-bound: algorithmic bytes = 2 * M * C * 2.  One wave per row, 4 rows per workgroup, every
 // lane holds its 16-B chunks in registers (chunk = lane + 64*i), two-pass statistics in f32
 // (mean, then centred sum of squares) like torch, output rounded once to bf16.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -10,7 +10,7 @@
 // normalising the operand fragments in every workgroup repeats the LayerNorm's VALU work N/16
 // times and made the launch 2x longer); the remaining blocks are the LayerNorm of layernorm.hip.  The skinny
 // blocks come first in the grid so they are resident while the LayerNorm blocks stream.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

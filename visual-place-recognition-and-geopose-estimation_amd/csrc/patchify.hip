@@ -9,7 +9,7 @@
 // HBM-bound: algorithmic bytes = B*3*H*W*2 in + B*(lead+n)*kpad*2 out (19.3 + 21.1 MB at B = 64).
 // One workgroup per (image, patch row): the 3 x P image rows (contiguous 2*W-byte lines) are
 // staged in LDS with 16-byte loads, then the G patches of that row leave as 16-byte chunks.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -13,7 +13,7 @@
 // grid, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 == an fmaf chain, cdna guide §3), partial slabs
 // summed in a fixed order by the epilogue kernel — bitwise reproducible run to run.
 #include <math.h>
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -10,7 +10,7 @@
 // (vpr_amd/preprocess.py reproduces Pillow's precompute_coeffs), each pass accumulates
 // sum(pixel * k) + 2^21 in int32, shifts by 22 and clamps to [0,255] — so the GPU result equals
 // PIL's bytes exactly, and the float stage is (u8/255 - mean) / std in f32 like ToTensor+Normalize.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

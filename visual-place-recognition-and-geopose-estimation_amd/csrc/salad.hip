@@ -19,7 +19,7 @@
 //   (Tried: 8 waves per image — the Sinkhorn iterations are exp/LDS-issue-bound per SIMD, not latency-bound:
 //   4.7 us per iteration instead of 3.4.)
 #include <math.h>
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -8,7 +8,7 @@
 // round trips long, not a streaming loop); a wave issues all 20 fragment loads of a slice before
 // the MFMAs (v_mfma_f32_16x16x32_bf16, W rows as the A operand so a lane ends up with 4
 // consecutive output columns), partial sums meet in LDS, wave w finishes row block w.
-#include "vpr_common.cuh"
+#include "vpr_common.h"
 #include "vpr_internal.h"
 
 namespace vpr {

@@ -1,4 +1,4 @@
-// vpr_common.cuh — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// vpr_common.h — shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
 // Wavefront = 64 lanes everywhere; LDS tiles are [rows][64 bf16] (128-B rows) filled by
 // LDS-DMA (global_load_lds_dwordx4) and read back as MFMA fragments with ds_read_b128.
 #pragma once
@@ -67,7 +67,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // chunk c ^ ((r >> 1) & 7): with this XOR every ds_read_b128 lane group of both MFMA operand
 // maps (16x16x32: row = lane&15, chunk = lane>>4 (+4); 32x32x16: row = lane&31,
 // chunk = lane>>5 (+2s)) touches 16 distinct 16-B slots of the 256-B bank row (checked
-// exhaustively on the host, tests/test_layout.py) — conflict-free.
+// exhaustively on the host, tests/test_library_cpu.py::test_lds_swizzle_is_conflict_free) — conflict-free.
 constexpr int TILE_ROW_BYTES = 128;
 __device__ __forceinline__ int tile_off(int row, int chunk) {
   return row * TILE_ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -75,10 +75,13 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B land at lds_wave_base + lane*16 (the LDS side
 // is linear; the swizzle is applied to the per-lane SOURCE address, cdna guide rule 21).
+// AUX = cache-policy bits of the instruction: 0 default, 2 = nt (non-temporal: for bytes read once, e.g. the gallery
+// stream of the kNN score kernel; MI355X_MICROARCH "nt-weights").
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)gsrc,
-      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 // Fill 8 tile rows [row0, row0+8) of an LDS tile from a row-major bf16 matrix: lane i writes

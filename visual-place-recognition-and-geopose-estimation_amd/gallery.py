@@ -170,6 +170,5 @@ class GraphedLocalTopK:
 
 
 def sharded_gallery_from(shard: GalleryShard, rank: int = 0, world: int = 1, group=None) -> ShardedGallery:
-    if shard.dtype != "bf16":
-        raise ValueError("ShardedGallery carries bf16 rows; use GraphedLocalTopK / ops.knn_topk_fp8 for fp8 shards")
-    return ShardedGallery(shard.rows, shard.n_total, rank, world, group=group)
+    """A loaded shard (bf16 rows, or e4m3 bytes + per-row scales) as the distributed search object."""
+    return ShardedGallery(shard.rows, shard.n_total, rank, world, group=group, scales=shard.scales)
