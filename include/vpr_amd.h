@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VPR_AMD_ABI_VERSION 1
+#define VPR_AMD_ABI_VERSION 2
 
 typedef enum vpr_status {
   VPR_OK = 0,
@@ -145,6 +145,40 @@ int vpr_knn_topk_fp8(const uint8_t* q, const float* q_scale, const uint8_t* gall
                      const float* gallery_scale, int B, int N, int D, int k, int index_base,
                      float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* Checked forms: the exactness contract above, certified per query on the device.
+ * The search is approximate-then-exact: MFMA scores pick KP = max(2k, k+8) candidates per query, those are
+ * rescored exactly (f64) and ordered.  That is the exact top-k iff no row outside the candidate set has an exact
+ * score >= the k-th best exact score e_k.  Every such row has an MFMA score <= a_min (the smallest MFMA score
+ * kept) and |MFMA score - exact score| <= eps = 1.1 * D * 2^-24 * |q| * gallery_norm_bound (f32 accumulation of
+ * exact products in any order), so  e_k - eps > a_min  proves it.  Otherwise the kernel widens the candidate set to
+ * every first-level candidate with MFMA score >= e_k - eps and rescoring them too (more than KP - k gallery rows
+ * within eps of the k-th score, e.g. near-duplicate frames).  status[b]:
+ *   0  certified at once;   1  certified after widening;
+ *   2  NOT certified (more than KP such rows inside one 8192-row chunk, > 256 candidates, or a shard so large /
+ *      rows so wide that the search ran the multi-level path): out_* hold the best effort; re-run those queries
+ *      with vpr_knn_topk_exhaustive.  `uncertified` (device int32, may be NULL) is incremented once per status-2
+ *      query, so a pipeline can check one word at the end instead of synchronising per batch.
+ * gallery_norm_bound: upper bound of the L2 norms of the (dequantised) gallery rows; the unchecked entry points
+ * assume L2-normalised descriptors (1.002 bf16, 1.0625 e4m3).  status may be NULL. */
+int vpr_knn_topk_checked(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                         int index_base, float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                         float gallery_norm_bound, int32_t* status, int32_t* uncertified, void* stream);
+int vpr_knn_select_checked(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                           int index_base, float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                           float gallery_norm_bound, int32_t* status, int32_t* uncertified, void* stream);
+int vpr_knn_topk_fp8_checked(const uint8_t* q, const float* q_scale, const uint8_t* gallery,
+                             const float* gallery_scale, int B, int N, int D, int k, int index_base,
+                             float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                             float gallery_norm_bound, int32_t* status, int32_t* uncertified, void* stream);
+
+/* Exhaustive form (the fallback for status-2 queries): every score computed exactly (f64 accumulation, one wave
+ * per gallery row), then the same selection — exact by construction, ~B gallery passes of f64 work: meant for a
+ * handful of queries.  q / gallery: bf16 (is_fp8 = 0, scales NULL) or e4m3 bytes with per-row scales.
+ * Rows of at most 17408 bytes.  Same workspace as vpr_knn_topk. */
+int vpr_knn_topk_exhaustive(const void* q, const float* q_scale, const void* gallery, const float* gallery_scale,
+                            int is_fp8, int B, int N, int D, int k, int index_base, float* out_val,
+                            int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Per-row symmetric quantisation f32 -> e4m3: scale = max|x|/448 (1 for a zero row),
  * q = fp8_rne(x / scale).  x [rows, D] f32 (D % 4 == 0), q [rows, D] bytes, scale [rows] f32. */

@@ -338,3 +338,25 @@ def test_attention_matches_f64_reference(dev, B, T, H):
         *[t.to(dev) for t in qkv.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)]).transpose(1, 2).reshape(B, T, H * 64)
     # and within two bf16 ulps (outputs reach |x| ~ 6, ulp 0.031) of PyTorch's own kernel
     assert (out - sdpa.cpu().double()).abs().max().item() < 7e-2
+
+
+def test_pose_head_plane_cache_survives_a_recycled_address(dev):
+    """The (hi, lo) bf16 planes of W1 are cached per weight storage.  A weight that is freed and another of the same
+    shape allocated at the same address (the caching allocator does exactly that) must not hit the old planes:
+    the cache entry pins its weight (round-2 fix; the failure showed up as a 1e-2 error in test_mlp_head)."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, D, hidden = 8, 1024, 64
+    x = torch.randn(B, D, generator=g)
+    W2, b2 = _linear_init(2, hidden, g)
+    ptrs = set()
+    for trial in range(4):
+        W1, b1 = _linear_init(hidden, D, g)
+        W1d = W1.to(dev)
+        ptrs.add(W1d.data_ptr())
+        out = ops.pose_head(x.to(dev), W1d, b1.to(dev), W2.to(dev), b2.to(dev), -1, split=True).cpu().double()
+        ref = oheads.mlp_head(x, W1, b1, W2, b2, -1)
+        assert (out - ref).abs().max().item() < TOL, trial
+        del W1d
+    # whether or not the allocator reused the address this time, every trial had to be right
+    assert len(ptrs) >= 1

@@ -301,3 +301,109 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):
     _full_size_check(dev, B, N, k, fp8, seed=B + N)
+
+
+# ----------------------------------------------------------------- certification of the exactness contract
+def _near_tie_problem(n_chunks, per_chunk, D=512, seed=50):
+    """A gallery with 64 'band' rows whose EXACT scores against query 0 are 0.75 + c + r * 2^-24, r = 0..63 (one f32
+    ulp apart), while their MFMA scores are scrambled: each band row carries a pair (+x_r, -x_r) on two coordinates
+    where the query is equal (exactly zero contribution) but far apart in K, so the f32 accumulator passes through a
+    different large intermediate value for every row.  More than KP - k = 14 rows inside the MFMA error of the k-th
+    score: the approximate top-KP cut can drop true top-k rows (VERDICT r1 weak #8)."""
+    g = torch.Generator().manual_seed(seed)
+    N = 8192 * n_chunks
+    gal = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(2, D, generator=g), dim=1) * 0.5
+    q[0, 0], q[0, 1], q[0, 2], q[0, 500] = 2.0 ** -12, 0.75, 2.0 ** -3, 2.0 ** -3
+    tail = torch.randn(D, generator=g) * 0.02
+    tail[[0, 1, 2, 500]] = 0
+    rows = []
+    for r in range(64):
+        chunk, j = (r % n_chunks, r // n_chunks) if per_chunk < 64 else (0, r)
+        idx = chunk * 8192 + 97 * j + 5
+        v = tail.clone()
+        v[0], v[1] = r * 2.0 ** -12, 1.0
+        x = 1.0 + (r * 37 % 64) / 64.0
+        v[2], v[500] = x, -x
+        gal[idx] = v
+        rows.append(idx)
+    return q.to(torch.bfloat16), gal.to(torch.bfloat16), rows
+
+
+def test_knn_near_ties_are_widened_and_exact(dev):
+    """64 rows within 64 ulps of each other around the k-th score, 8 per level-0 chunk: every chunk list holds its
+    band rows, the top-KP cut does not -> the kernel must notice (status 1), rescore the whole band and return the
+    exact answer; the unrelated query stays status 0."""
+    from vpr_amd import ops
+    q, gal, rows = _near_tie_problem(8, 8)
+    k = 10
+    v_ref, i_ref = oknn.knn_topk(q, gal, k)
+    assert set(i_ref[0].tolist()) == set(rows[-k:])                   # the 10 highest r: the exact answer is known
+    status = torch.full((2,), -1, dtype=torch.int32, device=dev)
+    unc = torch.zeros(1, dtype=torch.int32, device=dev)
+    bound = float(gal.float().norm(dim=1).max()) * 1.001
+    v, i = ops.knn_topk(q.to(dev), gal.to(dev), k, norm_bound=bound, status=status, uncertified=unc)
+    assert status.tolist() == [1, 0] and int(unc) == 0
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
+
+
+def test_knn_saturated_band_is_flagged_and_fallback_is_exact(dev):
+    """All 64 band rows in ONE level-0 chunk: its list (KP = 24) is cut inside the band, the kernel cannot certify
+    (status 2, counter incremented); exact_fallback re-runs the query exhaustively -> exact answer, status 3."""
+    from vpr_amd import ops
+    q, gal, rows = _near_tie_problem(3, 64)
+    k = 10
+    v_ref, i_ref = oknn.knn_topk(q, gal, k)
+    bound = float(gal.float().norm(dim=1).max()) * 1.001
+    status = torch.full((2,), -1, dtype=torch.int32, device=dev)
+    unc = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.knn_topk(q.to(dev), gal.to(dev), k, norm_bound=bound, status=status, uncertified=unc)
+    assert status.tolist() == [2, 0] and int(unc) == 1
+    v, i = ops.knn_topk(q.to(dev), gal.to(dev), k, norm_bound=bound, status=status, exact_fallback=True)
+    assert status.tolist() == [3, 0]
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
+    ve, ie = ops.knn_topk_exhaustive(q.to(dev), gal.to(dev), k, index_base=11)
+    assert torch.equal(ie.cpu(), i_ref + 11) and torch.equal(ve.cpu(), v_ref)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("bound", [1e-9, 30.0, 1e6])
+def test_knn_certification_paths_keep_the_answer(dev, fp8, bound):
+    """The three outcomes forced through the norm bound on ordinary data: a tiny bound certifies at once (status 0),
+    a loose one widens (1) or flags (2), an absurd one flags everything; with exact_fallback the answer is the
+    oracle's in every case, bf16 and e4m3 alike."""
+    from vpr_amd import ops
+    B, N, D, k = 9, 20000, 1024, 10
+    if fp8:
+        q, qs = _fp8_rows(B, D, 61)
+        g, gs = _fp8_rows(N, D, 62)
+        v_ref, i_ref = oknn.knn_topk_fp8(q, qs, g, gs, k, 3)
+        args = (q.to(dev), qs.to(dev), g.to(dev), gs.to(dev), k, 3)
+        fn = ops.knn_topk_fp8
+    else:
+        q, g = _unit_rows(B, D, 61), _unit_rows(N, D, 62)
+        v_ref, i_ref = oknn.knn_topk(q, g, k, 3)
+        args = (q.to(dev), g.to(dev), k, 3)
+        fn = ops.knn_topk
+    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    v, i = fn(*args, norm_bound=bound, status=status, exact_fallback=True)
+    st = status.tolist()
+    if bound < 1:
+        assert st == [0] * B
+    elif bound > 1e3:
+        assert st == [3] * B
+    else:
+        assert all(s in (0, 1, 3) for s in st)
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref)
+
+
+def test_knn_default_bound_certifies_normalised_descriptors(dev):
+    """BASELINE-like data (unit rows, D = 8448): every query certified without widening — the guard costs nothing
+    on the benchmark path."""
+    from vpr_amd import ops
+    B, N, D, k = 64, 30000, 8448, 10
+    q, g = _unit_rows(B, D, 71).to(dev), _unit_rows(N, D, 72).to(dev)
+    status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    unc = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.knn_topk(q, g, k, status=status, uncertified=unc)
+    assert int(status.max()) == 0 and int(unc) == 0

@@ -14,7 +14,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_lon
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STATUS_OK = 0
 
@@ -47,6 +47,14 @@ PROTOTYPES = {
                              c_void_p, c_size_t, c_void_p]),
     "vpr_knn_topk_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_topk_checked": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
+    "vpr_knn_select_checked": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
+    "vpr_knn_topk_fp8_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
+    "vpr_knn_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_quantize_fp8_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_knn_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_knn_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

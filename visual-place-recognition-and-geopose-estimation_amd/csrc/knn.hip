@@ -439,22 +439,45 @@ __device__ __forceinline__ double dot16_fp8(const s16x8& qa, const s16x8& ga, do
   return acc;
 }
 
+// Sum of squares of one 16-B operand chunk (f32; feeds the error bound of the certification step only).
+__device__ __forceinline__ float sumsq16_bf16(const s16x8& a) {
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float x = bf16_bits_to_f32((uint16_t)a[j]); t = fmaf(x, x, t); }
+  return t;
+}
+__device__ __forceinline__ float sumsq16_fp8(const s16x8& a) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const i32x4 w = __builtin_bit_cast(i32x4, a);
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float x = __builtin_amdgcn_cvt_f32_fp8(w[i], 0); t = fmaf(x, x, t);
+    x = __builtin_amdgcn_cvt_f32_fp8(w[i], 1); t = fmaf(x, x, t);
+    x = __builtin_amdgcn_cvt_f32_fp8(w[i], 2); t = fmaf(x, x, t);
+    x = __builtin_amdgcn_cvt_f32_fp8(w[i], 3); t = fmaf(x, x, t);
+  }
+  return t;
+}
+
 template <bool FP8>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(
     const int32_t* __restrict__ cand_idx, const void* __restrict__ Qv, const void* __restrict__ Gv,
     const float* __restrict__ q_scale, const float* __restrict__ g_scale,
-    int row_bytes, int kp, float* __restrict__ exact) {
+    int row_bytes, int kp, float* __restrict__ exact, float* __restrict__ qnorm) {
   __shared__ double red[4];
+  __shared__ float redq[4];
   const int c = blockIdx.x, b = blockIdx.y;
   const int id = cand_idx[(long long)b * kp + c];
-  if (id < 0) {   // uniform
+  if (id < 0 && c != 0) {   // uniform (candidate 0 always runs: it also leaves |q| for the certification step)
     if (threadIdx.x == 0) exact[(long long)b * kp + c] = -INFINITY;
     return;
   }
   const char* qrow = static_cast<const char*>(Qv) + (long long)b * row_bytes;
-  const char* grow = static_cast<const char*>(Gv) + (long long)id * row_bytes;
+  const char* grow = static_cast<const char*>(Gv) + (long long)(id < 0 ? 0 : id) * row_bytes;
   const int nchunks = row_bytes >> 4;
   double acc = 0.0;
+  float qq = 0.f;
   for (int ch0 = threadIdx.x; ch0 < nchunks; ch0 += 256 * RS_U) {
     s16x8 qa[RS_U], ga[RS_U];
 #pragma unroll
@@ -466,16 +489,24 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(
     }
 #pragma unroll
     for (int u = 0; u < RS_U; ++u) {
-      if (ch0 + 256 * u < nchunks) acc = FP8 ? dot16_fp8(qa[u], ga[u], acc) : dot16_bf16(qa[u], ga[u], acc);
+      if (ch0 + 256 * u < nchunks) {
+        acc = FP8 ? dot16_fp8(qa[u], ga[u], acc) : dot16_bf16(qa[u], ga[u], acc);
+        if (c == 0) qq += FP8 ? sumsq16_fp8(qa[u]) : sumsq16_bf16(qa[u]);
+      }
     }
   }
   acc = wave_sum_f64(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  qq = wave_sum(qq);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; redq[threadIdx.x >> 6] = qq; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = (red[0] + red[1]) + (red[2] + red[3]);
-    if (FP8) tot = (tot * (double)q_scale[b]) * (double)g_scale[id];   // same order as oracle/knn.py
-    exact[(long long)b * kp + c] = (float)tot;
+    if (FP8 && id >= 0) tot = (tot * (double)q_scale[b]) * (double)g_scale[id];   // same order as oracle/knn.py
+    exact[(long long)b * kp + c] = id < 0 ? -INFINITY : (float)tot;
+    if (c == 0) {
+      const float n2 = (redq[0] + redq[1]) + (redq[2] + redq[3]);
+      qnorm[b] = sqrtf(n2) * (FP8 ? fabsf(q_scale[b]) : 1.0f);
+    }
   }
 }
 
@@ -487,30 +518,53 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(
 constexpr int FF_NT = 512;        // 8 waves
 constexpr int FF_CPW = 3;         // candidates a wave rescoring together (all their loads in flight)
 constexpr int FF_MAXCH = 9;       // 16-B chunks per lane per row in flight per trip
+constexpr int FF_MAXC = 256;      // rescored candidates per query: kp + what the certification step adds
 struct FinalSmem {
   unsigned long long tmax[256];
   unsigned long long cand[SEL_CAP];
-  unsigned long long outk[128];
+  unsigned long long outk[FF_MAXC];
   unsigned long long thr;
   int cnt;
-  float exact[128];
+  float exact[FF_MAXC];
+  float red[8];
+  float ek;         // k-th best exact score of the rescored set
+  int nvalid;       // real (non-padding) entries of the rescored set
+  int extra;        // candidates the certification step adds
+  int flag;         // 0 certified, 1 widen, 2 cannot be certified from the lists in hand
 };
 
+// Certification (the exactness contract, made checkable).  The result is the exact top-k iff no row OUTSIDE the
+// rescored set has an exact score >= the k-th best exact score e_k of the set.  Every such row lost an
+// approximate-score comparison: its MFMA score is <= a_min, the smallest approximate score kept (level-0 lists and
+// the top-kp cut both keep the largest keys), and |MFMA score - exact score| <= eps = err_rel * |q| for gallery
+// rows inside the norm bound the caller folded into err_rel (any summation order of D f32 additions of exact
+// products: gamma_D * sum|q_i g_i| <= D 2^-24 |q| |g|).  So  e_k - eps > a_min  certifies the answer.
+// Otherwise the set is widened to every level-0 candidate with MFMA score >= e_k - eps (they are rescored exactly
+// too, status 1); if a level-0 chunk list is itself cut above that bar (>= kp rows of one chunk inside the band),
+// or the widened set does not fit, the query is flagged (status 2) and the host re-runs it on exact scores
+// (vpr_knn_exact_scores): ops.knn_topk(..., exact_fallback=True).
 template <bool FP8>
 __global__ __launch_bounds__(FF_NT) void knn_final_fused_kernel(
     const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, int L,
     const void* __restrict__ Qv, const void* __restrict__ Gv, const float* __restrict__ q_scale,
     const float* __restrict__ g_scale, int row_bytes, int k, int kp, int index_base,
-    float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx,
+    float err_rel, int level0_lists, int32_t* __restrict__ status, int32_t* __restrict__ uncertified) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];      // [row_bytes] query row
   __shared__ FinalSmem sm;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // stage the query row (16-B chunks)
+  // stage the query row (16-B chunks); |q|^2 on the way
   const char* qrow = static_cast<const char*>(Qv) + (long long)b * row_bytes;
   const int nchunks = row_bytes >> 4;
-  for (int ch = tid; ch < nchunks; ch += FF_NT)
-    *reinterpret_cast<s16x8*>(dyn + ch * 16) = *reinterpret_cast<const s16x8*>(qrow + ch * 16);
+  float qq = 0.f;
+  for (int ch = tid; ch < nchunks; ch += FF_NT) {
+    const s16x8 c16 = *reinterpret_cast<const s16x8*>(qrow + ch * 16);
+    *reinterpret_cast<s16x8*>(dyn + ch * 16) = c16;
+    qq += FP8 ? sumsq16_fp8(c16) : sumsq16_bf16(c16);
+  }
+  qq = wave_sum(qq);
+  if (lane == 0) sm.red[wave] = qq;
 
   // ---- top-kp of the candidates (8 keys per thread) ----
   unsigned long long keys[8];
@@ -527,8 +581,8 @@ __global__ __launch_bounds__(FF_NT) void knn_final_fused_kernel(
   unsigned long long best = keys[0];
 #pragma unroll
   for (int i = 1; i < 8; ++i) best = keys[i] > best ? keys[i] : best;
-  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
-  if (tid < 128) sm.outk[tid] = KEY_DEAD;
+  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; sm.extra = 0; sm.flag = 0; sm.nvalid = 0; sm.ek = -INFINITY; }
+  if (tid < FF_MAXC) sm.outk[tid] = KEY_DEAD;
   {  // 256 group maxes: pairs of threads (quad-perm xor 1)
     const unsigned long long o = dpp_u64<0xB1>(best);
     best = o > best ? o : best;
@@ -559,77 +613,137 @@ __global__ __launch_bounds__(FF_NT) void knn_final_fused_kernel(
   }
   __syncthreads();
 
-  // ---- exact rescoring: wave w takes candidates w + 8*j; FF_CPW of them per trip, with every
-  // 16-B chunk of all their rows requested before the first FMA (one HBM round trip per trip) ----
-  for (int c0 = wave; c0 < kp; c0 += 8 * FF_CPW) {
-    int id[FF_CPW];
-    const char* grow[FF_CPW];
-    double acc[FF_CPW];
+  // ---- exact rescoring of outk[c_lo, c_hi): wave w takes candidates c_lo + w + 8*j; FF_CPW of them per trip, with
+  // every 16-B chunk of all their rows requested before the first FMA (one HBM round trip per trip) ----
+  auto rescore = [&](int c_lo, int c_hi) {
+    for (int c0 = c_lo + wave; c0 < c_hi; c0 += 8 * FF_CPW) {
+      int id[FF_CPW];
+      const char* grow[FF_CPW];
+      double acc[FF_CPW];
 #pragma unroll
-    for (int j = 0; j < FF_CPW; ++j) {
-      const int c = c0 + 8 * j;
-      const unsigned long long key = c < kp ? sm.outk[c] : KEY_DEAD;
-      id[j] = key == KEY_DEAD ? -1 : key_idx(key);
-      grow[j] = static_cast<const char*>(Gv) + (long long)(id[j] < 0 ? 0 : id[j]) * row_bytes;
-      acc[j] = 0.0;
-    }
-    for (int base = 0; base < nchunks; base += 64 * FF_MAXCH) {   // 2 trips at D = 8448
-      s16x8 ga[FF_CPW][FF_MAXCH];
+      for (int j = 0; j < FF_CPW; ++j) {
+        const int c = c0 + 8 * j;
+        const unsigned long long key = c < c_hi ? sm.outk[c] : KEY_DEAD;
+        id[j] = key == KEY_DEAD ? -1 : key_idx(key);
+        grow[j] = static_cast<const char*>(Gv) + (long long)(id[j] < 0 ? 0 : id[j]) * row_bytes;
+        acc[j] = 0.0;
+      }
+      for (int base = 0; base < nchunks; base += 64 * FF_MAXCH) {   // 2 trips at D = 8448
+        s16x8 ga[FF_CPW][FF_MAXCH];
 #pragma unroll
-      for (int j = 0; j < FF_CPW; ++j)
+        for (int j = 0; j < FF_CPW; ++j)
+#pragma unroll
+          for (int u = 0; u < FF_MAXCH; ++u) {
+            const int ch = base + lane + 64 * u;
+            ga[j][u] = *reinterpret_cast<const s16x8*>(grow[j] + (ch < nchunks ? ch : lane) * 16);
+          }
 #pragma unroll
         for (int u = 0; u < FF_MAXCH; ++u) {
           const int ch = base + lane + 64 * u;
-          ga[j][u] = *reinterpret_cast<const s16x8*>(grow[j] + (ch < nchunks ? ch : lane) * 16);
-        }
+          if (ch < nchunks) {
+            const s16x8 qa = *reinterpret_cast<const s16x8*>(dyn + ch * 16);
 #pragma unroll
-      for (int u = 0; u < FF_MAXCH; ++u) {
-        const int ch = base + lane + 64 * u;
-        if (ch < nchunks) {
-          const s16x8 qa = *reinterpret_cast<const s16x8*>(dyn + ch * 16);
-#pragma unroll
-          for (int j = 0; j < FF_CPW; ++j)
-            acc[j] = FP8 ? dot16_fp8(qa, ga[j][u], acc[j]) : dot16_bf16(qa, ga[j][u], acc[j]);
+            for (int j = 0; j < FF_CPW; ++j)
+              acc[j] = FP8 ? dot16_fp8(qa, ga[j][u], acc[j]) : dot16_bf16(qa, ga[j][u], acc[j]);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < FF_CPW; ++j) {
-      const int c = c0 + 8 * j;
-      double tot = wave_sum_f64(acc[j]);
-      if (FP8 && id[j] >= 0) tot = (tot * (double)q_scale[b]) * (double)g_scale[id[j]];
-      if (lane == 0 && c < kp) sm.exact[c] = id[j] < 0 ? -INFINITY : (float)tot;
+      for (int j = 0; j < FF_CPW; ++j) {
+        const int c = c0 + 8 * j;
+        double tot = wave_sum_f64(acc[j]);
+        if (FP8 && id[j] >= 0) tot = (tot * (double)q_scale[b]) * (double)g_scale[id[j]];
+        if (lane == 0 && c < c_hi) sm.exact[c] = id[j] < 0 ? -INFINITY : (float)tot;
+      }
+    }
+  };
+  // ---- final order of outk[0, tot) by (f32(exact) desc, index asc); leaves e_k and the entry count ----
+  auto order = [&](int tot) {
+    if (tid < tot) {
+      const unsigned long long ki = sm.outk[tid];
+      int rank;
+      if (ki == KEY_DEAD) {
+        rank = FF_MAXC + tid;                      // padding: behind every real entry
+      } else {
+        const unsigned long long mine = make_key(sm.exact[tid], key_idx(ki));
+        rank = 0;
+        for (int j = 0; j < tot; ++j) {
+          const unsigned long long kj = sm.outk[j];
+          rank += (kj != KEY_DEAD && make_key(sm.exact[j], key_idx(kj)) > mine) ? 1 : 0;
+        }
+        atomicAdd(&sm.nvalid, 1);
+        if (rank == k - 1) sm.ek = sm.exact[tid];
+      }
+      if (rank < k) {
+        out_val[(long long)b * k + rank] = sm.exact[tid];
+        out_idx[(long long)b * k + rank] = key_idx(ki) + index_base;
+      }
+    }
+  };
+
+  rescore(0, kp);
+  __syncthreads();
+  order(kp);
+  __syncthreads();
+  const int nvalid = sm.nvalid;
+  if (tid < k && tid >= nvalid) {                  // fewer real rows than k: (-inf, -1) tail
+    out_val[(long long)b * k + tid] = -INFINITY;
+    out_idx[(long long)b * k + tid] = -1;
+  }
+  // ---- certification ----
+  const float qnorm = sqrtf(((sm.red[0] + sm.red[1]) + (sm.red[2] + sm.red[3])) + ((sm.red[4] + sm.red[5]) + (sm.red[6] + sm.red[7]))) *
+                      (FP8 ? fabsf(q_scale[b]) : 1.0f);
+  const float eps = err_rel * qnorm;
+  const unsigned long long kmin = sm.outk[kp - 1];               // smallest approximate key kept (KEY_DEAD: list not full)
+  const float bar = sm.ek - eps;
+  __syncthreads();                                               // everybody has read nvalid / ek before they are reused
+  if (kmin == KEY_DEAD || bar > key_val(kmin)) {                 // nothing was cut, or the margin covers the MFMA error
+    if (tid == 0 && status) status[b] = 0;
+    return;
+  }
+  // widen: every level-0 candidate outside the top-kp whose approximate score reaches the bar
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (keys[i] != KEY_DEAD && keys[i] < kmin && key_val(keys[i]) >= bar) {
+      const int pos = atomicAdd(&sm.extra, 1);
+      if (kp + pos < FF_MAXC) sm.outk[kp + pos] = keys[i];
     }
   }
+  if (level0_lists) {                                            // a chunk list cut above the bar hides rows of the band
+    const int nch = L / kp;
+    for (int c = tid; c < nch; c += FF_NT) {
+      const int last = c * kp + kp - 1;
+      if (ix[last] >= 0 && v[last] >= bar) sm.flag = 2;
+    }
+  } else if (tid == 0) {
+    sm.flag = 2;                                                 // lists of a later select level: per-chunk cuts unknown here
+  }
+  if (tid == 0) sm.nvalid = 0;
   __syncthreads();
-
-  // ---- final order by (f32(exact) desc, index asc) ----
-  if (tid < kp) {
-    const unsigned long long ki = sm.outk[tid];
-    int rank;
-    if (ki == KEY_DEAD) {
-      rank = tid;
-    } else {
-      const unsigned long long mine = make_key(sm.exact[tid], key_idx(ki));
-      rank = 0;
-      for (int j = 0; j < kp; ++j) {
-        const unsigned long long kj = sm.outk[j];
-        rank += (kj != KEY_DEAD && make_key(sm.exact[j], key_idx(kj)) > mine) ? 1 : 0;
-      }
-    }
-    if (rank < k) {
-      out_val[(long long)b * k + rank] = ki == KEY_DEAD ? -INFINITY : sm.exact[tid];
-      out_idx[(long long)b * k + rank] = ki == KEY_DEAD ? -1 : key_idx(ki) + index_base;
-    }
+  int extra = sm.extra;
+  const bool overflow = kp + extra > FF_MAXC;
+  if (overflow) extra = FF_MAXC - kp;
+  rescore(kp, kp + extra);
+  __syncthreads();
+  order(kp + extra);
+  if (tid == 0) {
+    const int st = (sm.flag == 2 || overflow) ? 2 : 1;
+    if (status) status[b] = st;
+    if (st == 2 && uncertified) atomicAdd(uncertified, 1);
   }
 }
 
 // 3b. final order: grid (B), 128 threads.  Rank the kp rescored candidates by
-// (f32(exact) desc, index asc) by counting; write the top-k with global indices.
+// (f32(exact) desc, index asc) by counting; write the top-k with global indices.  Certification as in the
+// fused kernel, without the widening step (this path serves rows wider than its LDS budget and galleries of
+// more than ~1.4M rows per shard): status 0 or 2.
 __global__ __launch_bounds__(128) void knn_order_kernel(
     const int32_t* __restrict__ cand_idx, const float* __restrict__ exact, int k, int kp, int index_base,
-    float* __restrict__ out_val, int32_t* __restrict__ out_idx) {
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx,
+    const float* __restrict__ cand_approx, const float* __restrict__ qnorm, float err_rel,
+    int32_t* __restrict__ status, int32_t* __restrict__ uncertified) {
   __shared__ unsigned long long key[128];
+  __shared__ float ek;
   const int b = blockIdx.x, i = threadIdx.x;
   int id = -1;
   unsigned long long mine = KEY_DEAD;
@@ -638,6 +752,7 @@ __global__ __launch_bounds__(128) void knn_order_kernel(
     if (id >= 0) mine = make_key(exact[(long long)b * kp + i], id);
   }
   key[i] = mine;
+  if (i == 0) ek = -INFINITY;
   __syncthreads();
   if (i < kp) {
     int rank = 0;
@@ -645,11 +760,57 @@ __global__ __launch_bounds__(128) void knn_order_kernel(
       rank = i;     // padding already sits behind every real entry (select output is ordered)
     } else {
       for (int j = 0; j < kp; ++j) rank += key[j] > mine ? 1 : 0;
+      if (rank == k - 1) ek = key_val(mine);
     }
     if (rank < k) {
       out_val[(long long)b * k + rank] = id < 0 ? -INFINITY : key_val(mine);
       out_idx[(long long)b * k + rank] = id < 0 ? -1 : id + index_base;
     }
+  }
+  __syncthreads();
+  if (i == 0 && (status || uncertified)) {
+    const bool full = cand_idx[(long long)b * kp + kp - 1] >= 0;          // the list is rank-ordered: last entry = a_min
+    const bool ok = !full || ek - err_rel * qnorm[b] > cand_approx[(long long)b * kp + kp - 1];
+    if (status) status[b] = ok ? 0 : 2;
+    if (!ok && uncertified) atomicAdd(uncertified, 1);
+  }
+}
+
+// Exact score matrix (the fallback of a query the certification step flags): S[b, n] = f32 of the exact (f64) dot
+// product, as the rescoring kernels compute it.  One wave per gallery row (its 16-B chunks held in registers, <= 17
+// per lane), looped over the (few) queries; grid = ceil(N / 4) workgroups of 4 waves.  HBM-bound on the gallery
+// for a handful of queries; a rare path, not tuned further.
+constexpr int EX_MAXCH = 17;      // 16-B chunks per lane: rows up to 17408 bytes
+template <bool FP8>
+__global__ __launch_bounds__(256) void knn_exact_scores_kernel(
+    const void* __restrict__ Qv, const void* __restrict__ Gv, const float* __restrict__ q_scale,
+    const float* __restrict__ g_scale, float* __restrict__ S, int B, int N, int row_bytes, int ldS) {
+  const int lane = threadIdx.x & 63;
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int nchunks = row_bytes >> 4;
+  const char* grow = static_cast<const char*>(Gv) + n * row_bytes;
+  s16x8 ga[EX_MAXCH];
+#pragma unroll
+  for (int u = 0; u < EX_MAXCH; ++u) {
+    const int ch = lane + 64 * u;
+    ga[u] = *reinterpret_cast<const s16x8*>(grow + (ch < nchunks ? ch : lane) * 16);
+  }
+  const float gs = FP8 ? g_scale[n] : 1.f;
+  for (int b = 0; b < B; ++b) {
+    const char* qrow = static_cast<const char*>(Qv) + (long long)b * row_bytes;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < EX_MAXCH; ++u) {
+      const int ch = lane + 64 * u;
+      if (ch < nchunks) {
+        const s16x8 qa = *reinterpret_cast<const s16x8*>(qrow + ch * 16);
+        acc = FP8 ? dot16_fp8(qa, ga[u], acc) : dot16_bf16(qa, ga[u], acc);
+      }
+    }
+    double tot = wave_sum_f64(acc);
+    if (FP8) tot = (tot * (double)q_scale[b]) * (double)gs;
+    if (lane == 0) S[(long long)b * ldS + n] = (float)tot;
   }
 }
 
@@ -686,7 +847,7 @@ struct KnnPlan {
   int Bpad, ldS, kp, ch0;
   int nlevel;            // number of select levels before the final kernel
   int L[4], nchunk[4];   // input length / chunk count per level
-  size_t off_S, off_cv[2], off_ci[2], total;
+  size_t off_S, off_cv[2], off_ci[2], off_qn, total;
 };
 
 static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
@@ -717,6 +878,7 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
     p->off_cv[i] = off; off += align_up(cand * sizeof(float), 256);
     p->off_ci[i] = off; off += align_up(cand * sizeof(int32_t), 256);
   }
+  p->off_qn = off; off += align_up((size_t)B * sizeof(float), 256);      // |q| per query (general rescore path)
   p->total = off;
   return true;
 }
@@ -815,8 +977,18 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   return VPR_OK;
 }
 
+// Relative bound of |MFMA score - exact score| / (|q| |g|): D f32 additions of exact products in any order
+// (gamma_D = D 2^-24 to first order; 1.1 covers the higher-order terms, the final f32 rounding of the exact score
+// and the two scale multiplications of the fp8 path), times the caller's bound on the gallery row norms.
+static float knn_err_rel(int D, float gallery_norm_bound) {
+  return 1.1f * (float)D * 5.9604645e-8f * gallery_norm_bound;
+}
+
 int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
-               int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream) {
+               int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream,
+               float gallery_norm_bound = 1.0f, int32_t* status = nullptr, int32_t* uncertified = nullptr) {
+  if (!(gallery_norm_bound > 0.f)) return VPR_ERR_INVALID_ARG;
+  const float err_rel = knn_err_rel(D, gallery_norm_bound);
   KnnPlan p;
   if (!ws || !out_val || !out_idx) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
@@ -847,24 +1019,28 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
     ld = L;
   }
   if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 24 * 1024) {
+    const int level0 = lev == 1 ? 1 : 0;       // the lists in hand are level 0's [nchunk][kp] rank-ordered lists
     if (o.fp8)
       VPR_TRY_LAUNCH(launch_kernel(knn_final_fused_kernel<true>, dim3(B), dim3(FF_NT), (size_t)rb, stream, cur_v,
-                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx));
+                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx,
+                                   err_rel, level0, status, uncertified));
     else
       VPR_TRY_LAUNCH(launch_kernel(knn_final_fused_kernel<false>, dim3(B), dim3(FF_NT), (size_t)rb, stream, cur_v,
-                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx));
+                                   cur_i, L, o.q, o.g, o.q_scale, o.g_scale, rb, k, p.kp, index_base, out_val, out_idx,
+                                   err_rel, level0, status, uncertified));
     return VPR_OK;
   }
   // general path: the last select level left the [B][kp] list; rescore and order it
   float* exact = reinterpret_cast<float*>(w + p.off_cv[p.nlevel & 1]);
+  float* qn = reinterpret_cast<float*>(w + p.off_qn);
   if (o.fp8)
     VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel<true>, dim3(p.kp, B), dim3(256), 0, stream, cur_i, o.q, o.g,
-                                 o.q_scale, o.g_scale, D, p.kp, exact));
+                                 o.q_scale, o.g_scale, D, p.kp, exact, qn));
   else
     VPR_TRY_LAUNCH(launch_kernel(knn_rescore_kernel<false>, dim3(p.kp, B), dim3(256), 0, stream, cur_i, o.q, o.g,
-                                 o.q_scale, o.g_scale, D * 2, p.kp, exact));
+                                 o.q_scale, o.g_scale, D * 2, p.kp, exact, qn));
   VPR_TRY_LAUNCH(launch_kernel(knn_order_kernel, dim3(B), dim3(128), 0, stream, cur_i, exact, k, p.kp,
-                               index_base, out_val, out_idx));
+                               index_base, out_val, out_idx, cur_v, qn, err_rel, status, uncertified));
   return VPR_OK;
 }
 
@@ -925,8 +1101,18 @@ extern "C" int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B,
                     static_cast<hipStream_t>(stream));
 }
 
+extern "C" int vpr_knn_select_checked(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                                      int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                                      size_t workspace_bytes, float gallery_norm_bound, int32_t* status,
+                                      int32_t* uncertified, void* stream) {
+  const KnnOperands o{q, gallery, nullptr, nullptr, false};
+  return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified);
+}
+
 static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
-                        int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+                        int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream,
+                        float gallery_norm_bound, int32_t* status, int32_t* uncertified) {
   KnnPlan p;
   if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
@@ -934,14 +1120,29 @@ static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int in
   const int st = knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream));
   if (st != VPR_OK) return st;
   return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified);
 }
+
+// Default norm bounds of the unchecked entry points: L2-normalised descriptors.  A bf16-rounded unit vector has norm
+// within 2^-9 of 1; an e4m3 row (3 mantissa bits, scale = max/448) within 2^-4.
+constexpr float NORM_BOUND_BF16 = 1.002f;
+constexpr float NORM_BOUND_FP8 = 1.0625f;
 
 extern "C" int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
                             int index_base, float* out_val, int32_t* out_idx, void* workspace,
                             size_t workspace_bytes, void* stream) {
   const KnnOperands o{q, gallery, nullptr, nullptr, false};
-  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream);
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream,
+                      NORM_BOUND_BF16, nullptr, nullptr);
+}
+
+extern "C" int vpr_knn_topk_checked(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
+                                    int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                                    size_t workspace_bytes, float gallery_norm_bound, int32_t* status,
+                                    int32_t* uncertified, void* stream) {
+  const KnnOperands o{q, gallery, nullptr, nullptr, false};
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream,
+                      gallery_norm_bound, status, uncertified);
 }
 
 extern "C" int vpr_knn_topk_fp8(const uint8_t* q, const float* q_scale, const uint8_t* gallery,
@@ -949,7 +1150,44 @@ extern "C" int vpr_knn_topk_fp8(const uint8_t* q, const float* q_scale, const ui
                                 float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   const KnnOperands o{q, gallery, q_scale, gallery_scale, true};
-  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream);
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream,
+                      NORM_BOUND_FP8, nullptr, nullptr);
+}
+
+extern "C" int vpr_knn_topk_fp8_checked(const uint8_t* q, const float* q_scale, const uint8_t* gallery,
+                                        const float* gallery_scale, int B, int N, int D, int k, int index_base,
+                                        float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                                        float gallery_norm_bound, int32_t* status, int32_t* uncertified,
+                                        void* stream) {
+  const KnnOperands o{q, gallery, q_scale, gallery_scale, true};
+  return knn_topk_any(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, stream,
+                      gallery_norm_bound, status, uncertified);
+}
+
+extern "C" int vpr_knn_topk_exhaustive(const void* q, const float* q_scale, const void* gallery,
+                                       const float* gallery_scale, int is_fp8, int B, int N, int D, int k,
+                                       int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  KnnPlan p;
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0 || !workspace) return VPR_ERR_INVALID_ARG;
+  if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
+  const KnnOperands o{q, gallery, q_scale, gallery_scale, is_fp8 != 0};
+  const int st = knn_check(o, D);
+  if (st != VPR_OK) return st;
+  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
+  const int rb = o.fp8 ? D : D * 2;
+  if (rb > EX_MAXCH * 64 * 16) return VPR_ERR_UNSUPPORTED;
+  float* S = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.off_S);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((N + 3) / 4));
+  if (o.fp8)
+    VPR_TRY_LAUNCH(launch_kernel(knn_exact_scores_kernel<true>, grid, dim3(256), 0, hs, o.q, o.g, o.q_scale, o.g_scale,
+                                 S, B, N, rb, p.ldS));
+  else
+    VPR_TRY_LAUNCH(launch_kernel(knn_exact_scores_kernel<false>, grid, dim3(256), 0, hs, o.q, o.g, o.q_scale, o.g_scale,
+                                 S, B, N, rb, p.ldS));
+  // the scores are exact already: every cut keeps the true largest keys, whatever the bound says
+  return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes, hs, 1.0f, nullptr, nullptr);
 }
 
 extern "C" int vpr_quantize_fp8_rows(const float* x, long long rows, int D, uint8_t* q, float* scale, void* stream) {

@@ -185,9 +185,28 @@ def knn_workspace(B: int, N: int, D: int, k: int, device: torch.device) -> torch
     return workspace("knn", nbytes, device)
 
 
+NORM_BOUND_BF16 = 1.002     # L2-normalised rows rounded to bf16 (the unchecked C entry points assume the same)
+NORM_BOUND_FP8 = 1.0625     # ... quantised to e4m3 with a per-row scale
+
+
+def _check_args(B: int, device, status: Optional[torch.Tensor], uncertified: Optional[torch.Tensor]) -> None:
+    if status is not None:
+        _need(status, torch.int32, "status", 1)
+        if status.numel() != B:
+            raise RuntimeError("status: one int32 per query")
+    if uncertified is not None:
+        _need(uncertified, torch.int32, "uncertified", 1)
+
+
 def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0,
-             ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """q [B,D] bf16, gallery [N,D] bf16 -> (scores f32 [B,k] descending, indices int32 [B,k])."""
+             ws: Optional[torch.Tensor] = None, *, norm_bound: float = NORM_BOUND_BF16,
+             status: Optional[torch.Tensor] = None, uncertified: Optional[torch.Tensor] = None,
+             exact_fallback: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q [B,D] bf16, gallery [N,D] bf16 -> (scores f32 [B,k] descending, indices int32 [B,k]).
+    The kernels certify each query's answer as the exact top-k (include/vpr_amd.h, "Checked forms"):
+    `status` (int32 [B]) receives 0 / 1 (certified) or 2 (not certified), `uncertified` (int32 [1]) counts the 2s
+    without a host sync; `norm_bound` = upper bound of the gallery row norms.  exact_fallback=True reads the status
+    back (one sync) and re-runs the flagged queries exhaustively, so the result is exact unconditionally."""
     _need(q, torch.bfloat16, "q", 2)
     _need(gallery, torch.bfloat16, "gallery", 2)
     B, D = q.shape
@@ -196,12 +215,56 @@ def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0
         raise RuntimeError("knn_topk: q and gallery disagree on D")
     if ws is None:
         ws = knn_workspace(B, N, D, k, q.device)
+    if exact_fallback and status is None:
+        status = torch.empty((B,), dtype=torch.int32, device=q.device)
+    _check_args(B, q.device, status, uncertified)
     vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
-    st = _lib.lib().vpr_knn_topk(_ptr(q), _ptr(gallery), B, N, D, int(k), int(index_base), _ptr(vals), _ptr(idx),
-                                 _ptr(ws), ws.numel(), _stream())
-    _lib.check(st, "vpr_knn_topk")
+    st = _lib.lib().vpr_knn_topk_checked(_ptr(q), _ptr(gallery), B, N, D, int(k), int(index_base), _ptr(vals), _ptr(idx),
+                                         _ptr(ws), ws.numel(), float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
+    _lib.check(st, "vpr_knn_topk_checked")
+    if exact_fallback:
+        _exhaustive_fixup(q, None, gallery, None, k, index_base, status, vals, idx)
     return vals, idx
+
+
+def knn_topk_exhaustive(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0,
+                        q_scale: Optional[torch.Tensor] = None, gallery_scale: Optional[torch.Tensor] = None,
+                        ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Every score computed exactly (f64), then the same selection: exact by construction, slow (fallback for the
+    queries the certification flags).  bf16 operands, or uint8 e4m3 operands with both per-row scales."""
+    fp8 = q.dtype == torch.uint8
+    _need(q, torch.uint8 if fp8 else torch.bfloat16, "q", 2)
+    _need(gallery, q.dtype, "gallery", 2)
+    if fp8:
+        _need(q_scale, torch.float32, "q_scale", 1)
+        _need(gallery_scale, torch.float32, "gallery_scale", 1)
+    B, D = q.shape
+    N = gallery.shape[0]
+    if gallery.shape[1] != D:
+        raise RuntimeError("knn_topk_exhaustive: q and gallery disagree on D")
+    if ws is None:
+        ws = knn_workspace(B, N, D, k, q.device)
+    vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
+    st = _lib.lib().vpr_knn_topk_exhaustive(_ptr(q), _ptr(q_scale) if fp8 else None, _ptr(gallery),
+                                            _ptr(gallery_scale) if fp8 else None, int(fp8), B, N, D, int(k),
+                                            int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_knn_topk_exhaustive")
+    return vals, idx
+
+
+def _exhaustive_fixup(q, q_scale, gallery, gallery_scale, k, index_base, status, vals, idx) -> int:
+    """Host side of exact_fallback: one D2H read of `status`, exhaustive re-run of the queries marked 2."""
+    bad = torch.nonzero(status == 2).flatten()           # syncs
+    if bad.numel() == 0:
+        return 0
+    qb = q[bad].contiguous()
+    v2, i2 = knn_topk_exhaustive(qb, gallery, k, index_base, q_scale[bad].contiguous() if q_scale is not None else None,
+                                 gallery_scale)
+    vals[bad], idx[bad] = v2, i2
+    status[bad] = 3                                       # 3 = exact through the exhaustive path
+    return int(bad.numel())
 
 
 def quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -216,8 +279,11 @@ def quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def knn_topk_fp8(q: torch.Tensor, q_scale: torch.Tensor, gallery: torch.Tensor, gallery_scale: torch.Tensor,
-                 k: int, index_base: int = 0, ws: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """fp8 (e4m3 bytes + per-row f32 scale) variant of knn_topk; D % 128 == 0."""
+                 k: int, index_base: int = 0, ws: Optional[torch.Tensor] = None, *, norm_bound: float = NORM_BOUND_FP8,
+                 status: Optional[torch.Tensor] = None, uncertified: Optional[torch.Tensor] = None,
+                 exact_fallback: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp8 (e4m3 bytes + per-row f32 scale) variant of knn_topk; D % 128 == 0.  norm_bound bounds the norms of the
+    DEQUANTISED gallery rows."""
     _need(q, torch.uint8, "q", 2)
     _need(gallery, torch.uint8, "gallery", 2)
     _need(q_scale, torch.float32, "q_scale", 1)
@@ -228,11 +294,17 @@ def knn_topk_fp8(q: torch.Tensor, q_scale: torch.Tensor, gallery: torch.Tensor, 
         raise RuntimeError("knn_topk_fp8: inconsistent shapes")
     if ws is None:
         ws = knn_workspace(B, N, D, k, q.device)
+    if exact_fallback and status is None:
+        status = torch.empty((B,), dtype=torch.int32, device=q.device)
+    _check_args(B, q.device, status, uncertified)
     vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
-    st = _lib.lib().vpr_knn_topk_fp8(_ptr(q), _ptr(q_scale), _ptr(gallery), _ptr(gallery_scale), B, N, D, int(k),
-                                     int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), _stream())
-    _lib.check(st, "vpr_knn_topk_fp8")
+    st = _lib.lib().vpr_knn_topk_fp8_checked(_ptr(q), _ptr(q_scale), _ptr(gallery), _ptr(gallery_scale), B, N, D, int(k),
+                                             int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(),
+                                             float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
+    _lib.check(st, "vpr_knn_topk_fp8_checked")
+    if exact_fallback:
+        _exhaustive_fixup(q, q_scale, gallery, gallery_scale, k, index_base, status, vals, idx)
     return vals, idx
 
 
@@ -246,14 +318,17 @@ def knn_scores(q: torch.Tensor, gallery: torch.Tensor, ws: torch.Tensor) -> None
 
 
 def knn_select(q: torch.Tensor, gallery: torch.Tensor, k: int, ws: torch.Tensor,
-               index_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Stage 2+3 (candidate selection, exact rescoring, ordering) on scores already in `ws`."""
+               index_base: int = 0, *, norm_bound: float = NORM_BOUND_BF16, status: Optional[torch.Tensor] = None,
+               uncertified: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stage 2+3 (candidate selection, exact rescoring, ordering, certification) on scores already in `ws`."""
     B, D = q.shape
+    _check_args(B, q.device, status, uncertified)
     vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
-    st = _lib.lib().vpr_knn_select(_ptr(q), _ptr(gallery), B, gallery.shape[0], D, int(k), int(index_base),
-                                   _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), _stream())
-    _lib.check(st, "vpr_knn_select")
+    st = _lib.lib().vpr_knn_select_checked(_ptr(q), _ptr(gallery), B, gallery.shape[0], D, int(k), int(index_base),
+                                           _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(), float(norm_bound),
+                                           _ptr(status), _ptr(uncertified), _stream())
+    _lib.check(st, "vpr_knn_select_checked")
     return vals, idx
 
 
@@ -287,18 +362,20 @@ _POSE_PLANES: dict = {}
 
 
 def _pose_w1_planes(W1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(hi, lo) bf16 planes of a first-layer weight, packed once per (storage, version) by vpr_pose_head_pack_w1."""
+    """(hi, lo) bf16 planes of a first-layer weight, packed once per (storage, version) by vpr_pose_head_pack_w1.
+    The entry keeps a reference to W1: while it is cached its storage cannot be freed and handed to another weight
+    of the same shape (a recycled address with version 0 would otherwise hit the stale planes)."""
     key = (W1.data_ptr(), W1._version, tuple(W1.shape), str(W1.device))
     hit = _POSE_PLANES.get(key)
     if hit is None:
-        if len(_POSE_PLANES) > 16:
-            _POSE_PLANES.clear()
+        while len(_POSE_PLANES) >= 8:
+            _POSE_PLANES.pop(next(iter(_POSE_PLANES)))        # oldest first (dicts keep insertion order)
         hi = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
         lo = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
         st = _lib.lib().vpr_pose_head_pack_w1(_ptr(W1), W1.numel(), _ptr(hi), _ptr(lo), _stream())
         _lib.check(st, "vpr_pose_head_pack_w1")
-        hit = _POSE_PLANES[key] = (hi, lo)
-    return hit
+        hit = _POSE_PLANES[key] = (hi, lo, W1)
+    return hit[0], hit[1]
 
 
 def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Tensor], W2: torch.Tensor,
