@@ -635,7 +635,7 @@ __global__ __launch_bounds__(FF_NT) void knn_final_fused_kernel(
 #pragma unroll
           for (int u = 0; u < FF_MAXCH; ++u) {
             const int ch = base + lane + 64 * u;
-            ga[j][u] = *reinterpret_cast<const s16x8*>(grow[j] + (ch < nchunks ? ch : lane) * 16);
+            ga[j][u] = *reinterpret_cast<const s16x8*>(grow[j] + (ch < nchunks ? ch : 0) * 16);
           }
 #pragma unroll
         for (int u = 0; u < FF_MAXCH; ++u) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void knn_exact_scores_kernel(
 #pragma unroll
   for (int u = 0; u < EX_MAXCH; ++u) {
     const int ch = lane + 64 * u;
-    ga[u] = *reinterpret_cast<const s16x8*>(grow + (ch < nchunks ? ch : lane) * 16);
+    ga[u] = *reinterpret_cast<const s16x8*>(grow + (ch < nchunks ? ch : 0) * 16);
   }
   const float gs = FP8 ? g_scale[n] : 1.f;
   for (int b = 0; b < B; ++b) {

@@ -26,16 +26,36 @@ class StepOutput:
 
 
 class VPRGeoPosePipeline:
-    def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10):
+    def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10,
+                 overlap_head: Optional[bool] = None):
         self.extractor, self.head, self.gallery, self.k = extractor, head, gallery, k
         self.knn_events = None     # optional list collecting (start, end) events of the score kernel
+        # The pose head needs only the descriptor; the retrieval leg (two collectives with launch-latency gaps between
+        # them when the gallery is sharded) runs beside it: head on a side stream, joined at the end of the step.
+        self.overlap_head = gallery.collective if overlap_head is None else overlap_head
+        self._side = {}
+
+    def _side_stream(self, dev, main):
+        key = (str(dev), main.cuda_stream)
+        s = self._side.get(key)
+        if s is None:
+            s = self._side[key] = torch.cuda.Stream(device=dev)
+        return s
 
     @torch.no_grad()
     def step(self, images: torch.Tensor) -> StepOutput:
         desc, desc16 = self.extractor.features(images, want_bf16=True)
         g = self.gallery
+        pose = None
+        if self.overlap_head:
+            main = torch.cuda.current_stream(desc.device)
+            side = self._side_stream(desc.device, main)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pose = self.head(desc)
+            desc.record_stream(side)
         q_all = g.gather_queries(desc16)
-        if self.knn_events is not None and g.world >= 1 and getattr(g, "scales", None) is None:
+        if self.knn_events is not None and getattr(g, "scales", None) is None:
             # same kernels as ShardedGallery.search, with HIP events around the score kernel
             B = q_all.shape[0]
             ws = ops.knn_workspace(B, g.rows.shape[0], q_all.shape[1], self.k, q_all.device)
@@ -44,23 +64,29 @@ class VPRGeoPosePipeline:
             ops.knn_scores(q_all, g.rows, ws)
             e1.record()
             self.knn_events.append((e0, e1))
-            v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base)
-            if g.world > 1:
+            v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base, norm_bound=g.norm_bound or ops.NORM_BOUND_BF16,
+                                  uncertified=g.uncertified)
+            if g.collective:
                 vs, is_ = all_gather_topk(v, i, g.world, g.group)
                 v, i = ops.topk_merge(vs, is_)
         elif self.knn_events is not None:
             # fp8 shard: events around the whole local search (quantise queries + scores + select)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            v, i = g.engine.local_topk(q_all, g.rows, self.k, g.index_base, g.scales)
+            v, i = g._local(q_all, self.k)
             e1.record()
             self.knn_events.append((e0, e1))
-            if g.world > 1:
+            if g.collective:
                 vs, is_ = all_gather_topk(v, i, g.world, g.group)
                 v, i = ops.topk_merge(vs, is_)
         else:
             v, i = g.search(q_all, self.k)
         b = desc.shape[0]
-        v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]
-        pose = self.head(desc)
+        if g.collective:
+            v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]
+        if self.overlap_head:
+            main.wait_stream(side)
+            pose.record_stream(main)
+        else:
+            pose = self.head(desc)
         return StepOutput(desc, v, i, pose)

@@ -27,15 +27,19 @@ def shard_bounds(N: int, rank: int, world: int) -> Tuple[int, int]:
 class HipEngine:
     """Local top-k and merge on the gfx950 kernels."""
 
-    def local_topk(self, q, gallery, k, index_base, scales=None):
+    def local_topk(self, q, gallery, k, index_base, scales=None, norm_bound=None, uncertified=None, ws=None):
         """bf16 shard: q bf16.  fp8 shard (uint8 rows + per-row f32 `scales`): the gathered queries are
-        quantised per row here (e4m3 + scale, vpr_quantize_fp8_rows) and searched by vpr_knn_topk_fp8."""
+        quantised per row here (e4m3 + scale, vpr_quantize_fp8_rows) and searched by vpr_knn_topk_fp8.
+        `uncertified` (int32 [1] on the device) counts queries whose answer the kernels could not certify as the
+        exact top-k (include/vpr_amd.h "Checked forms"); no host sync."""
         if gallery.dtype == torch.uint8:
             if scales is None:
                 raise ValueError("fp8 shard needs per-row scales")
             q8, qs = ops.quantize_fp8_rows(q.float())
-            return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base)
-        return ops.knn_topk(q, gallery, k, index_base)
+            return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base, ws,
+                                    norm_bound=norm_bound or ops.NORM_BOUND_FP8, uncertified=uncertified)
+        return ops.knn_topk(q, gallery, k, index_base, ws, norm_bound=norm_bound or ops.NORM_BOUND_BF16,
+                            uncertified=uncertified)
 
     def merge(self, vals, idxs):
         return ops.topk_merge(vals, idxs)
@@ -55,8 +59,13 @@ def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
 
 class ShardedGallery:
     def __init__(self, local_rows: torch.Tensor, n_total: int, rank: int = 0, world: int = 1,
-                 engine=None, group: Optional[dist.ProcessGroup] = None, scales: Optional[torch.Tensor] = None):
-        """local_rows: [n_local, D] bf16, or uint8 e4m3 bytes with per-row f32 `scales` (value = scale * fp8)."""
+                 engine=None, group: Optional[dist.ProcessGroup] = None, scales: Optional[torch.Tensor] = None,
+                 norm_bound: Optional[float] = None, force_collectives: bool = False):
+        """local_rows: [n_local, D] bf16, or uint8 e4m3 bytes with per-row f32 `scales` (value = scale * fp8).
+        norm_bound: upper bound of the (dequantised) row norms for the exactness certificate; None = L2-normalised
+        descriptors (what SALAD emits); `measure_norm_bound()` computes it from the rows.
+        force_collectives: run the two all-gathers and the merge even with one rank (exercises the RCCL path on a
+        single GPU: bench.py --force-dist)."""
         lo, hi = shard_bounds(n_total, rank, world)
         if local_rows.shape[0] != hi - lo:
             raise ValueError(f"rank {rank}: shard has {local_rows.shape[0]} rows, expected {hi - lo}")
@@ -69,23 +78,41 @@ class ShardedGallery:
         self.index_base = lo
         self.engine = engine if engine is not None else HipEngine()
         self.group = group
+        self.norm_bound = norm_bound
+        self.collective = world > 1 or force_collectives
+        # queries whose local answer was not certified exact, summed over every search of this object (device word)
+        self.uncertified = torch.zeros(1, dtype=torch.int32, device=local_rows.device) if local_rows.is_cuda else None
+
+    def measure_norm_bound(self, slab: int = 65536) -> float:
+        """Largest L2 norm of the (dequantised) local rows, with 0.1 % slack; kept as this shard's norm bound."""
+        best = 0.0
+        for lo in range(0, self.rows.shape[0], slab):
+            r = self.rows[lo:lo + slab]
+            x = r.view(torch.float8_e4m3fn).float() * self.scales[lo:lo + slab, None] if self.scales is not None else r.float()
+            best = max(best, float(x.norm(dim=1).max()))
+        self.norm_bound = best * 1.001
+        return self.norm_bound
 
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.collective:
             return q_local
         out = torch.empty((self.world * q_local.shape[0], q_local.shape[1]), dtype=q_local.dtype, device=q_local.device)
         dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
         return out
 
-    def search(self, q_all: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """q_all [B, D]: the same on every rank.  Returns merged (vals [B,k], idx [B,k]) on every rank."""
+    def _local(self, q_all: torch.Tensor, k: int, ws=None):
+        if isinstance(self.engine, HipEngine):
+            return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales, self.norm_bound,
+                                          self.uncertified, ws)
         if self.scales is not None:
-            v, i = self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales)
-        else:
-            v, i = self.engine.local_topk(q_all, self.rows, k, self.index_base)
-        if self.world == 1:
+            return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales)
+        return self.engine.local_topk(q_all, self.rows, k, self.index_base)
+
+    def search(self, q_all: torch.Tensor, k: int, ws=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """q_all [B, D]: the same on every rank.  Returns merged (vals [B,k], idx [B,k]) on every rank."""
+        v, i = self._local(q_all, k, ws)
+        if not self.collective:
             return v, i
-        B = q_all.shape[0]
         vs, is_ = all_gather_topk(v, i, self.world, self.group)
         return self.engine.merge(vs, is_)
 
@@ -95,3 +122,46 @@ class ShardedGallery:
         v, i = self.search(q_all, k)
         b = q_local.shape[0]
         return v[self.rank * b:(self.rank + 1) * b], i[self.rank * b:(self.rank + 1) * b]
+
+    def uncertified_queries(self) -> int:
+        """Host read (one sync) of the counter: 0 means every answer so far was certified exact on the device."""
+        return int(self.uncertified) if self.uncertified is not None else 0
+
+
+class GraphedRetrieval:
+    """One batch of retrieval — {query all-gather, local shard search, packed top-k all-gather, merge} — captured once
+    into a HIP graph and replayed per batch (SURVEY §7 step 5 / BASELINE config 5: "hipGraph-captured per-batch
+    retrieval").  Static shapes: B_local queries per rank, k, this shard.  The kernels take stream-ordered arguments
+    and pre-allocated workspaces; RCCL's collectives are captured like any other stream work (every rank must
+    capture and replay in lockstep).  With one rank and no forced collectives the graph holds the local search only.
+    Replay: copy the queries into `self.q`, `replay()`, read `self.vals` / `self.idx` (this rank's B_local rows)."""
+
+    def __init__(self, gallery: ShardedGallery, batch_local: int, k: int):
+        self.g, self.k, self.b = gallery, k, batch_local
+        rows = gallery.rows
+        dev, D = rows.device, rows.shape[1]
+        self.q = torch.zeros((batch_local, D), dtype=torch.bfloat16, device=dev)
+        B = batch_local * (gallery.world if gallery.collective else 1)
+        self.ws = ops.knn_workspace(B, rows.shape[0], D, k, dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):            # warm-up outside capture: module load, allocator, communicator set-up
+            for _ in range(2):
+                self._run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.vals, self.idx = self._run()
+
+    def _run(self):
+        g = self.g
+        q_all = g.gather_queries(self.q)
+        v, i = g.search(q_all, self.k, self.ws)
+        lo = g.rank * self.b if g.collective else 0
+        return v[lo:lo + self.b], i[lo:lo + self.b]
+
+    def __call__(self, q_local: torch.Tensor):
+        self.q.copy_(q_local)
+        self.graph.replay()
+        return self.vals, self.idx
