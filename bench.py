@@ -88,6 +88,92 @@ def cpu_baseline(ext_state, arch, head_mods, images_cpu, gallery_sample_cpu, n_t
                       f"{threads} threads"}
 
 
+def _avg_ms(fn, n=10, warm=2):
+    """Average device time of fn() over n calls, HIP events on the current stream (the one the kernels launch on)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
+    """Roofline rows of the other hand-written stages (BASELINE configs 2, 4, 5), each timed on its own after the timed
+    region: algorithmic FLOPs / bytes over the average device time of the whole entry point."""
+    from vpr_amd import ops
+    from vpr_amd.gallery import GalleryShard
+    from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
+    rows = {}
+    B, C = images.shape[0], ext.backbone.embed_dim
+    hbm = lambda by, ms: {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": by / ms / 1e6 / HBM_PEAK_GBPS, "ms": ms, "algorithmic_bytes": by}
+    # SALAD (config 2): both token MLPs, Sinkhorn, aggregation, norms — MFMA-bound dense stage + latency-bound Sinkhorn
+    tokens = ext.backbone(images, split=True)
+    ms = _avg_ms(lambda: ext.aggregator(tokens, want_bf16=True))
+    fl = B * (2 * 256 * C * 1024 + 2 * 256 * 512 * 192 + 2 * C * 512 + 2 * 512 * 256 + 2 * 128 * 64 * 256)
+    rows["salad_aggregate"] = {"entry": "vpr_salad_aggregate_split", "shape": f"B={B} n=256 C={C} m=64 l=128 t=256",
+                               "bound": "mfma", "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, "ms": ms, "algorithmic_flops": fl}
+    # fused (lat, lon, sin, cos) head on the descriptor (configs 2/3): weight stream
+    desc = ext.aggregator(tokens)
+    W1, _, W2, _ = head.pack()
+    ms = _avg_ms(lambda: head(desc))
+    by = (W1.numel() + W2.numel()) * 4 + desc.numel() * 4
+    rows["pose_head"] = dict(entry="vpr_pose_head_split", shape=f"B={B} D={D_DESC} hidden={W1.shape[0]} n_out=4", **hbm(by, ms))
+    # Swin-B fused LN + mean-pool + 4-wide head (config 4): B=256, T=49 (224 px) and T=144 (384 px), H=1024, bf16
+    g = torch.Generator(device=dev).manual_seed(4)
+    for T in (49, 144):
+        xs = torch.randn(256, T, 1024, device=dev, generator=g).to(torch.bfloat16)
+        gm, bt = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
+        Wh, bh = torch.randn(4, 1024, device=dev, generator=g) * 0.03, torch.zeros(4, device=dev)
+        ms = _avg_ms(lambda: ops.ln_meanpool_head(xs, gm, bt, 1e-5, Wh, bh, 2, want_pooled=False))
+        rows[f"ln_meanpool_head_T{T}"] = dict(entry="vpr_ln_meanpool_head", shape=f"B=256 T={T} H=1024 bf16, n_out=4 (sin,cos unit)",
+                                              **hbm(xs.numel() * 2, ms))
+        del xs
+    # whole bf16 kNN call on the bench gallery (config 3 on one GPU) + the same retrieval replayed from a HIP graph
+    if shard_bf16 is not None:
+        N = shard_bf16.shape[0]
+        q = torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
+        ws = ops.knn_workspace(B, N, D_DESC, a.k, dev)
+        ms = _avg_ms(lambda: ops.knn_topk(q, shard_bf16, a.k, 0, ws))
+        by = N * D_DESC * 2 + B * D_DESC * 2 + B * a.k * 8
+        rows["knn_topk_bf16"] = dict(entry="vpr_knn_topk_checked", shape=f"B={B} N={N} D={D_DESC} k={a.k}", **hbm(by, ms))
+        gr = GraphedRetrieval(ShardedGallery(shard_bf16, N), B, a.k)
+        ms_g = _avg_ms(lambda: gr(q))
+        rows["knn_topk_bf16_graph_replay"] = dict(entry="GraphedRetrieval (hipGraph: scores + select + final)",
+                                                  shape=f"B={B} N={N}", **hbm(by, ms_g))
+        del gr, ws
+    # e4m3 gallery, 1M rows on one GPU (config 5's arithmetic and bytes; 8 GPUs would hold 125k rows each)
+    N8 = a.fp8_rows
+    if N8 > 0:
+        g8 = torch.empty((N8, D_DESC), dtype=torch.uint8, device=dev)
+        gs = torch.empty((N8,), dtype=torch.float32, device=dev)
+        for lo in range(0, N8, 65536):
+            n = min(65536, N8 - lo)
+            x = torch.nn.functional.normalize(torch.randn(n, D_DESC, device=dev, generator=g), dim=1)
+            g8[lo:lo + n], gs[lo:lo + n] = ops.quantize_fp8_rows(x)
+            del x
+        q8, qs = ops.quantize_fp8_rows(torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1))
+        ws = ops.knn_workspace(B, N8, D_DESC, a.k, dev)
+        unc = torch.zeros(1, dtype=torch.int32, device=dev)
+        ms = _avg_ms(lambda: ops.knn_topk_fp8(q8, qs, g8, gs, a.k, 0, ws, uncertified=unc), n=5)
+        by = N8 * D_DESC + N8 * 4 + B * D_DESC + B * a.k * 8
+        rows["knn_topk_fp8"] = dict(entry="vpr_knn_topk_fp8_checked", shape=f"B={B} N={N8} D={D_DESC} e4m3 + per-row scale, k={a.k}",
+                                    uncertified_queries=int(unc), **hbm(by, ms))
+        gr = GraphedRetrieval(ShardedGallery(g8, N8, scales=gs), B, a.k)
+        qb = torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
+        ms_g = _avg_ms(lambda: gr(qb), n=5)
+        rows["retrieval_fp8_graph_replay"] = dict(entry="GraphedRetrieval (hipGraph: quantise queries + scores + select + final)",
+                                                  shape=f"B={B} N={N8} e4m3", **hbm(by, ms_g))
+        del gr, g8, gs, ws
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +195,11 @@ def main():
     ap.add_argument("--no-side-chain", action="store_true", help="cls-row kernels in the main stream instead of a side stream forked / joined once per block (A/B)")
     ap.add_argument("--in-flight", type=int, default=1, help="independent batches in flight (one stream each); 1 = strictly sequential steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one rank: still create the process group (RCCL) and run the two all-gathers + merge of the "
+                         "sharded path (launch under torch.distributed.run --nproc-per-node 1, or bare: 127.0.0.1 rendezvous)")
+    ap.add_argument("--no-kernel-rows", action="store_true", help="skip the per-kernel roofline rows measured after the timed region")
+    ap.add_argument("--fp8-rows", type=int, default=1_000_000, help="gallery rows of the e4m3 kNN row (BASELINE config 5 on one GPU)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,11 +210,14 @@ def main():
     local_dev = local_rank % max(1, torch.cuda.device_count())     # == local_rank on a real N-GPU node
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:                            # bare `python bench.py --force-dist`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)             # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)     # RCCL over xGMI
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from vpr_amd import _lib, ops
     _lib.lib()
@@ -158,16 +252,16 @@ def main():
         for r0 in range(0, hi - lo, 65536):                                     # slabs: the f32 copy of a big shard is 4x its bf16 size
             q8, qs = ops.quantize_fp8_rows(shard[r0:r0 + 65536].float())
             g8[r0:r0 + 65536], gs[r0:r0 + 65536] = q8, qs
-        gallery = ShardedGallery(g8, a.gallery, rank, world, scales=gs)
+        gallery = ShardedGallery(g8, a.gallery, rank, world, scales=gs, force_collectives=a.force_dist)
     else:
-        gallery = ShardedGallery(shard, a.gallery, rank, world)
+        gallery = ShardedGallery(shard, a.gallery, rank, world, force_collectives=a.force_dist)
     pipe = VPRGeoPosePipeline(ext, head, gallery, a.k)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -197,7 +291,7 @@ def main():
                 out = pipe.step(images)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -208,22 +302,30 @@ def main():
     n_shard, bq = hi - lo, a.batch * world
     esz = 1 if a.knn_dtype == "fp8" else 2
     alg_bytes = n_shard * D_DESC * esz + bq * D_DESC * esz + bq * a.k * 8   # SURVEY §8d per query batch (s = 2 bf16, 1 fp8)
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_knn_pmc.json")
+    # HBM traffic of the score kernel from the PMC counters (profiles/, collected as MI355X_MICROARCH.md §HBM prescribes):
+    # quoted only if the summary was measured on THIS kernel source and names the kernel this run launched.
+    traffic, traffic_source = None, None
+    score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq).decode()
+    pmc = os.path.join(ROOT, "profiles", "r02_knn_pmc.json")
     if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64 and a.knn_dtype == "bf16":
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from pmc_summary import kernel_source_sha16
         with open(pmc) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            pj = json.load(f)
+        if pj.get("source_sha16") == kernel_source_sha16(ROOT) and score_kernel in pj.get("kernels", {}):
+            traffic = pj["kernels"][score_kernel]["hbm_bytes_per_launch"]
+            traffic_source = f"profiles/r02_knn_pmc.json (source_sha16 {pj['source_sha16']}, {score_kernel})"
 
     if bq <= 64 or a.knn_dtype == "fp8":
-        roofline = {"bound": "hbm", "kernel": "knn_scores_kernel" if a.knn_dtype == "bf16" else "vpr_knn_topk_fp8 (quantise queries + knn_scores_kernel<fp8> + select)",
+        roofline = {"bound": "hbm", "kernel": score_kernel if a.knn_dtype == "bf16" else f"vpr_knn_topk_fp8 (quantise queries + {score_kernel} + select)",
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                    "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}
     else:
         # more than one 64-query tile per shard scan (multi-GPU: all-gathered queries): vpr_knn_scores runs the
         # score tile as an MFMA GEMM (gemm_nt_kernel) — one gallery pass per 128 queries, 2*bq FLOP per gallery byte
         flops = 2.0 * bq * n_shard * D_DESC
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (score tile, query batch > 64)",
+        roofline = {"bound": "mfma", "kernel": f"{score_kernel} (score tile, query batch > 64)",
                     "achieved": flops / knn_avg_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / knn_avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_flops": flops}
@@ -234,7 +336,7 @@ def main():
         pos_idx = torch.randint(0, n_shard, (a.batch,), device=dev, generator=gp)
         qn = torch.nn.functional.normalize(shard[pos_idx].float() + 0.1 * torch.randn(a.batch, D_DESC, device=dev, generator=gp), dim=1)
         if a.knn_dtype == "fp8":
-            _, ti = gallery.engine.local_topk(qn.to(torch.bfloat16), gallery.rows, 1, lo, gallery.scales)
+            _, ti = gallery._local(qn.to(torch.bfloat16), 1)
         else:
             _, ti = ops.knn_topk(qn.to(torch.bfloat16), shard, 1, lo)
         recall1 = float((ti[:, 0].long() == pos_idx + lo).double().mean())
@@ -268,15 +370,19 @@ def main():
                        "k": a.k, "parallelism": f"dp{world}+gallery-shard{world}", "batches_in_flight": a.in_flight},
             "roofline": roofline,
             "recall_at_1": recall1,
+            "uncertified_queries": gallery.uncertified_queries(),    # kNN answers the device could not certify exact (0 expected)
             "stages": stages,
+            "dist": {"process_group": (a.backend if use_dist else None), "collectives_in_step": gallery.collective},
         }
+        if world == 1 and not a.no_kernel_rows:
+            res["kernels"] = kernel_rows(dev, ext, head, images, shard if a.knn_dtype == "bf16" else None, a)
         if world == 1 and not a.no_cpu_baseline:
             sample = shard.cpu()                                # whole gallery: the sample is one full step
             res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images.cpu(), sample, a.gallery, a.k)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,101 @@
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes — TCC has 4 slots, the two counters need
+3 + 2) into the per-kernel HBM-traffic summary bench.py reads (profiles/rNN_knn_pmc.json).
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 scripts/kernel_bench.py --only knn --iters 5
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 scripts/kernel_bench.py --only knn --iters 5
+  python3 scripts/pmc_summary.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --out profiles/r02_knn_pmc.json
+
+Units and corrections (MI355X_MICROARCH.md §HBM): both counters are reported in KiB; on gfx950 FETCH_SIZE counts
+exactly half the bytes of a wide coalesced read, so read bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 is exact for
+16-B-per-lane streaming stores.  The summary records the hash of the kernel sources it was measured on
+(`source_sha16`, see kernel_source_sha16) and the full kernel names: bench.py quotes `traffic` only when both match
+what it is about to launch."""
+import argparse
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ("visual-place-recognition-and-geopose-estimation_amd/csrc/knn.hip",
+           "visual-place-recognition-and-geopose-estimation_amd/csrc/vpr_common.h")
+
+
+def kernel_source_sha16(root: str = ROOT) -> str:
+    h = hashlib.sha256()
+    for rel in SOURCES:
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def short_name(full: str) -> str:
+    """'void vpr::knn_scores_kernel<false, 208, 2, 4>(void const*, ...)' -> 'vpr::knn_scores_kernel<false, 208, 2, 4>'"""
+    name = full.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):            # cut at the '(' that opens the argument list (outside template brackets)
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def collect(directory: str, counter: str, prefix: str):
+    """{short kernel name: [values]} for one counter over every counter_collection CSV under `directory`."""
+    out = {}
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit(f"no *counter_collection.csv under {directory}")
+    csv.field_size_limit(sys.maxsize)
+    for path in files:
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = short_name(row["Kernel_Name"])
+                if prefix in name:
+                    out.setdefault(name, []).append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--prefix", default="vpr::knn")
+    ap.add_argument("--command", default="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- "
+                                         "python3 scripts/kernel_bench.py --only knn --iters 5")
+    ap.add_argument("--workload", default="B=64 queries x N=100000 x D=8448 bf16, k=10, 1 MI355X")
+    ap.add_argument("--algorithmic-bytes", type=int, default=100000 * 8448 * 2 + 64 * 8448 * 2 + 64 * 10 * 8)
+    a = ap.parse_args()
+    fetch = collect(a.fetch, "FETCH_SIZE", a.prefix)
+    write = collect(a.write, "WRITE_SIZE", a.prefix)
+    kernels = {}
+    for name in sorted(set(fetch) | set(write)):
+        fv, wv = fetch.get(name, []), write.get(name, [])
+        f_avg = sum(fv) / len(fv) if fv else 0.0
+        w_avg = sum(wv) / len(wv) if wv else 0.0
+        kernels[name] = {"FETCH_SIZE_KiB_avg": f_avg, "WRITE_SIZE_KiB_avg": w_avg,
+                         "read_bytes_corrected": f_avg * 1024 * 2, "write_bytes": w_avg * 1024,
+                         "hbm_bytes_per_launch": f_avg * 1024 * 2 + w_avg * 1024,
+                         "dispatches": max(len(fv), len(wv))}
+    res = {"command": a.command, "workload": a.workload, "source_sha16": kernel_source_sha16(),
+           "units": "FETCH_SIZE / WRITE_SIZE in KiB; gfx950: read bytes = FETCH_SIZE*1024*2 (wide coalesced reads are "
+                    "tallied at half their size, MI355X_MICROARCH.md §HBM), write bytes = WRITE_SIZE*1024",
+           "kernels": kernels, "algorithmic_bytes": a.algorithmic_bytes}
+    with open(a.out, "w") as f:
+        json.dump(res, f, indent=1)
+    for k, v in kernels.items():
+        print(f"{k}: {v['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch ({v['dispatches']} dispatches)")
+
+
+if __name__ == "__main__":
+    main()

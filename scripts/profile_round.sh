@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun): kernel trace + stats of the default bench run, and the two PMC
+# passes (FETCH_SIZE / WRITE_SIZE, separate: TCC slot budget) on the kNN kernels -> gpurun_out/; the summaries that get
+# committed under profiles/ are copied from there (scripts/pmc_summary.py writes the PMC one).
+#   usage: bash scripts/profile_round.sh r02
+set -e
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1
+echo "bench trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/scripts/kernel_bench.py --only knn --iters 5 > $O/${TAG}_pmc_fetch.log 2>&1
+echo "pmc fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/scripts/kernel_bench.py --only knn --iters 5 > $O/${TAG}_pmc_write.log 2>&1
+echo "pmc write done"
+python3 $R/scripts/pmc_summary.py --fetch $O/${TAG}_pmc_fetch --write $O/${TAG}_pmc_write --out $O/${TAG}_knn_pmc.json
+# keep the merge-back small: the per-dispatch PMC CSVs are only needed for the summary
+find $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -name '*counter_collection.csv' -size +8M -delete || true

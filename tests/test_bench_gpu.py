@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "2", "--warmup", "1", "--arch", "vit_small", "--gallery", "3000", "--batch", "8", "--no-tune"]
+SMALL = ["--steps", "2", "--warmup", "1", "--arch", "vit_small", "--gallery", "3000", "--batch", "8", "--no-tune",
+         "--fp8-rows", "20000"]
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
 
@@ -37,6 +38,29 @@ def test_bench_single_rank_contract(dev):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "images" in c["sample"]
     assert d["recall_at_1"] == 1.0 and "workload" in d["config"]
+    assert r["kernel"] == "vpr::knn_scores_kernel<false, 208, 2, 4>" and r["traffic"] is None   # not the profiled workload
+    assert d["uncertified_queries"] == 0
+    rows = d["kernels"]                                       # per-kernel roofline rows (configs 2, 4, 5)
+    assert {"salad_aggregate", "pose_head", "ln_meanpool_head_T49", "ln_meanpool_head_T144", "knn_topk_bf16",
+            "knn_topk_bf16_graph_replay", "knn_topk_fp8", "retrieval_fp8_graph_replay"} <= set(rows)
+    for name, row in rows.items():
+        assert row["ms"] > 0 and 0 < row["frac"] < 1.0 and abs(row["frac"] - row["achieved"] / row["peak"]) < 1e-12, name
+    assert rows["salad_aggregate"]["bound"] == "mfma" and rows["knn_topk_fp8"]["uncertified_queries"] == 0
+
+
+def test_bench_force_dist_runs_the_collectives_on_rccl(dev):
+    """--force-dist: one rank, but a real RCCL process group and both all-gathers + the merge inside every step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+                        "--no-kernel-rows"] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _json_line(p.stdout)
+    assert d["dist"] == {"process_group": "nccl", "collectives_in_step": True}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["recall_at_1"] == 1.0 and d["uncertified_queries"] == 0
 
 
 def test_bench_fp8_gallery(dev):

@@ -270,3 +270,32 @@ def test_sharded_gallery_fp8_shards_two_way_equals_unsharded():
         ShardedGallery(g8, N, 0, 1, engine=eng)                       # uint8 rows need scales
     with pytest.raises(ValueError):
         ShardedGallery(gal.to(torch.bfloat16), N, 0, 1, engine=eng, scales=gs)   # bf16 rows must not carry scales
+
+
+def test_forced_collectives_single_rank_gloo_and_fp8_shard_helper(tmp_path):
+    """One rank with force_collectives: both all-gathers and the merge still run (what bench.py --force-dist does on
+    RCCL); sharded_gallery_from() carries an e4m3 shard's scales (it used to refuse fp8 shards)."""
+    from vpr_amd.gallery import GalleryShard, sharded_gallery_from
+    from vpr_amd.retrieval import ShardedGallery
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.Generator().manual_seed(3)
+        N, D, B, k = 300, 128, 5, 4
+        gal = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+        q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(torch.bfloat16)
+        sg = ShardedGallery(gal.to(torch.bfloat16), N, 0, 1, engine=OracleEngine(), force_collectives=True)
+        assert sg.collective
+        v, i = sg.search_local_queries(q, k)
+        v_ref, i_ref = oknn.knn_topk(q, gal.to(torch.bfloat16), k)
+        assert torch.equal(i, i_ref) and torch.equal(v, v_ref)
+        g8, gs = oknn.quantize_fp8_rows(gal)
+        shard = GalleryShard(g8, gs, None, N, 0, "fp8_e4m3")
+        sg8 = sharded_gallery_from(shard)
+        sg8.engine = OracleEngine()
+        v8, i8 = sg8.search(q, k)
+        q8, qs = oknn.quantize_fp8_rows(q.float())
+        v8r, i8r = oknn.knn_topk_fp8(q8, qs, g8, gs, k)
+        assert torch.equal(i8, i8r) and torch.equal(v8, v8r)
+    finally:
+        dist.destroy_process_group()

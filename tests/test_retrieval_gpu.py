@@ -1,0 +1,124 @@
+"""GPU: the sharded-retrieval code path on RCCL as far as one GPU can take it.
+
+A one-rank `nccl` (= RCCL on ROCm) process group runs exactly the calls the N-rank job makes — `device_id=` init,
+`all_gather_into_tensor` of the bf16 queries, of the packed (value, index) lists, on-device merge, teardown — so the
+communicator set-up, dtype/layout handling and stream ordering have executed on the real backend; what one rank cannot
+show is the xGMI transport and cross-rank ordering (covered by the 2-rank gloo tests in test_host_cpu.py /
+test_bench_gpu.py and, when the driver has an 8-GPU node, by its scaling run).
+Also here: {all-gather, local search, all-gather, merge} captured into ONE HIP graph (BASELINE config 5, SURVEY §7 step
+5) and replayed == eager, for bf16 and e4m3 shards; the pipeline's head-on-a-side-stream schedule == the in-stream one."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rccl_one_rank(dev):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield dev
+    dist.destroy_process_group()
+
+
+def _data(dev, N, B, D=8448, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    pos = torch.randint(0, N, (B,), device=dev, generator=g)
+    q = torch.nn.functional.normalize(gal[pos] + 0.1 * torch.randn(B, D, device=dev, generator=g), dim=1).to(torch.bfloat16)
+    return gal, q, pos
+
+
+def test_sharded_search_through_rccl_one_rank(rccl_one_rank):
+    from vpr_amd import ops
+    from vpr_amd.retrieval import ShardedGallery
+    dev = rccl_one_rank
+    gal, q, pos = _data(dev, 5000, 16)
+    rows = gal.to(torch.bfloat16)
+    sg = ShardedGallery(rows, 5000, 0, 1, force_collectives=True)
+    assert sg.collective
+    v, i = sg.search_local_queries(q, 10)                     # all_gather (queries) -> search -> all_gather (top-k) -> merge
+    v0, i0 = ops.knn_topk(q, rows, 10)
+    assert torch.equal(i, i0) and torch.equal(v, v0)
+    assert torch.equal(i[:, 0].long(), pos) and sg.uncertified_queries() == 0
+    # e4m3 shard through the same collectives
+    g8, gs = ops.quantize_fp8_rows(gal)
+    sg8 = ShardedGallery(g8, 5000, 0, 1, scales=gs, force_collectives=True)
+    v8, i8 = sg8.search_local_queries(q, 10)
+    q8, qs = ops.quantize_fp8_rows(q.float())
+    v8r, i8r = ops.knn_topk_fp8(q8, qs, g8, gs, 10)
+    assert torch.equal(i8, i8r) and torch.equal(v8, v8r)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_graphed_retrieval_with_collectives_equals_eager(rccl_one_rank, fp8):
+    """One HIP graph holding the query all-gather, the shard search, the packed top-k all-gather and the merge."""
+    from vpr_amd import ops
+    from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
+    dev = rccl_one_rank
+    gal, q, pos = _data(dev, 20000, 32, seed=3 + fp8)
+    if fp8:
+        g8, gs = ops.quantize_fp8_rows(gal)
+        sg = ShardedGallery(g8, 20000, 0, 1, scales=gs, force_collectives=True)
+    else:
+        sg = ShardedGallery(gal.to(torch.bfloat16), 20000, 0, 1, force_collectives=True)
+    gr = GraphedRetrieval(sg, 32, 10)
+    for trial in range(3):                                    # replay on fresh queries each time
+        g = torch.Generator(device=dev).manual_seed(200 + trial)
+        pos = torch.randint(0, 20000, (32,), device=dev, generator=g)
+        q = torch.nn.functional.normalize(gal[pos] + 0.1 * torch.randn(32, 8448, device=dev, generator=g), dim=1).to(torch.bfloat16)
+        v_g, i_g = gr(q)
+        v_g, i_g = v_g.clone(), i_g.clone()
+        v_e, i_e = sg.search_local_queries(q, 10)
+        assert torch.equal(i_g, i_e) and torch.equal(v_g, v_e), trial
+        assert torch.equal(i_g[:, 0].long(), pos)
+
+
+def test_graphed_retrieval_local_only(dev):
+    """Without a process group: the graph holds the local search (what one GPU of an unsharded deployment replays)."""
+    from vpr_amd import ops
+    from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
+    gal, q, pos = _data(dev, 9000, 8, seed=9)
+    rows = gal.to(torch.bfloat16)
+    sg = ShardedGallery(rows, 9000)
+    gr = GraphedRetrieval(sg, 8, 5)
+    v_g, i_g = gr(q)
+    v_e, i_e = ops.knn_topk(q, rows, 5)
+    assert torch.equal(i_g, i_e) and torch.equal(v_g, v_e) and torch.equal(i_g[:, 0].long(), pos)
+
+
+def test_pipeline_head_on_side_stream_equals_in_stream(rccl_one_rank):
+    """overlap_head (default when the gallery is sharded): the pose head runs on a side stream beside the two
+    collectives and the search; same kernels, same inputs -> bit-identical StepOutput."""
+    import torch.nn as nn
+    from vpr_amd.modules import DinoV2Salad, FusedGeoPoseHead
+    from vpr_amd.pipeline import VPRGeoPosePipeline
+    from vpr_amd.retrieval import ShardedGallery
+    dev = rccl_one_rank
+    torch.manual_seed(0)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    pos = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    ang = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    head = FusedGeoPoseHead(pos, ang, normalize=True)
+    gal = torch.nn.functional.normalize(torch.randn(3000, 8448, device=dev), dim=1).to(torch.bfloat16)
+    images = torch.randn(4, 3, 224, 224, device=dev).to(torch.bfloat16)
+    outs = []
+    for overlap in (True, False, True):
+        sg = ShardedGallery(gal, 3000, 0, 1, force_collectives=True)
+        pipe = VPRGeoPosePipeline(ext, head, sg, 5, overlap_head=overlap)
+        o = pipe.step(images)
+        torch.cuda.synchronize()
+        outs.append(o)
+    for o in outs[1:]:
+        assert torch.equal(o.pose, outs[0].pose) and torch.equal(o.topk_indices, outs[0].topk_indices)
+        assert torch.equal(o.topk_scores, outs[0].topk_scores) and torch.equal(o.descriptors, outs[0].descriptors)

@@ -1079,6 +1079,21 @@ extern "C" size_t vpr_knn_workspace_bytes(int B, int N, int D, int k) {
   return knn_plan(B, N, D, k, &p) ? p.total : 0;
 }
 
+extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B) {
+  // mirrors the dispatch of knn_scores(): what a kernel trace (rocprofv3) will show for this call
+  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
+  const int gemm_min_b = genv ? atoi(genv) : 65;
+  if (B >= gemm_min_b) return is_fp8 ? "vpr::gemm_nt_fp8_kernel" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
+  const char* venv = getenv("VPR_KNN_VARIANT");
+  const int variant = venv ? atoi(venv) : 0;
+  if (is_fp8) {
+    return variant == 2 ? "vpr::knn_scores_kernel<true, 144, 3, 4>"
+         : variant == 1 ? "vpr::knn_scores_kernel<true, 208, 2, 0>" : "vpr::knn_scores_kernel<true, 208, 2, 4>";
+  }
+  return variant == 2 ? "vpr::knn_scores_kernel<false, 144, 3, 4>"
+       : variant == 1 ? "vpr::knn_scores_kernel<false, 208, 2, 0>" : "vpr::knn_scores_kernel<false, 208, 2, 4>";
+}
+
 extern "C" float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k, int* ld_out) {
   KnnPlan p;
   if (!workspace || !knn_plan(B, N, D, k, &p)) return nullptr;
