@@ -189,3 +189,70 @@ def test_calculate_validation_scores_end_to_end(dev, tmp_path):
     sc = postproc.LatLonScaler.campus()
     assert np.array_equal(res["preds"], sc.inverse_transform(res["preds_standardised"]))
     assert res["final_loss"] == pytest.approx(postproc.final_loss(res["preds"], res["targets"]))
+
+
+def test_validate_and_test_swin_entry_point(dev, tmp_path, capsys):
+    """swin_transformer/val_and_test_swin_2.py on the MI355X path: validation CSV + image dirs + bare state dict in;
+    unreadable / missing files skipped as the reference's datasets + None-filtering collates do (:73-95, :150-155,
+    :179-195); metrics printed in its format; validation_predictions.csv / test_predictions_sorted.csv written in its
+    layout ('%.6f', test rows sorted by filename); predictions == HF SwinModel pooler -> torch MLP head (f32)."""
+    import pandas as pd
+    from PIL import Image
+    from transformers import SwinConfig, SwinModel
+    from vpr_amd import evaluate, modules, postproc
+    from vpr_amd.preprocess import IMAGENET_MEAN, IMAGENET_STD, ResizeNormalize
+    rng = np.random.default_rng(5)
+    vdir, tdir, sdir = tmp_path / "images_val", tmp_path / "images_test", tmp_path / "run"
+    vdir.mkdir(), tdir.mkdir()
+    vnames = [f"img_{i:04d}.jpg" for i in range(5)]
+    for n in vnames:
+        Image.fromarray(rng.integers(0, 256, (260, 300, 3), dtype=np.uint8)).save(vdir / n, quality=95)
+    (vdir / "img_0777.jpg").write_bytes(b"not an image")                         # corrupt: skipped with a warning
+    tnames = ["b_02.png", "a_01.png", "c_03.JPEG"]
+    for n in tnames:
+        Image.fromarray(rng.integers(0, 256, (200, 200, 3), dtype=np.uint8)).save(tdir / n)
+    (tdir / "zz_bad.png").write_bytes(b"\x89PNG broken")
+    df = pd.DataFrame({"filename": vnames + ["img_0777.jpg", "img_0999.jpg"], "timestamp": "12:00",
+                       "latitude": rng.normal(219658, 900, 7).round(), "longitude": rng.normal(143506, 1100, 7).round(),
+                       "angle": 0, "Region_ID": 1})
+    csv = tmp_path / "labels_val.csv"
+    df.to_csv(csv, index=False)
+    torch.manual_seed(4)
+    backbone = SwinModel(SwinConfig()).eval()                                    # Swin-T geometry at 224 px: same code path
+    src = modules.SwinMLPRegressionModel(backbone)
+    ck = tmp_path / "model_best.pth"
+    torch.save(src.state_dict(), ck)                                             # bare state dict (swin_attempt_2.py:255)
+    model = modules.SwinMLPRegressionModel(SwinModel(SwinConfig()))
+    res = evaluate.validate_and_test_swin(model, str(csv), str(vdir), str(tdir), str(sdir), checkpoint_path=str(ck),
+                                          image_size=224, batch_size=2)
+    printed = capsys.readouterr().out
+    assert "Skipping invalid/corrupt image file" in printed and "Image file not found and skipped" in printed
+    assert "--- Evaluation Results on Validation Set (Original Scale) ---" in printed and "MAE Longitude:" in printed
+    assert res["val_filenames"] == vnames and res["test_filenames"] == ["a_01.png", "b_02.png", "c_03.JPEG"]
+    # reference arithmetic, stage by stage, in f32 torch
+    sc = postproc.LatLonScaler.campus()
+    prep = ResizeNormalize(224, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
+    src = src.to(dev).eval()
+    def ref_preds(d, names):
+        outs = []
+        with torch.no_grad():
+            for n in names:
+                u8 = torch.from_numpy(np.array(Image.open(d / n).convert("RGB"))[None]).to(dev)
+                pooled = src.backbone(pixel_values=prep(u8)).pooler_output
+                outs.append(src.regressor(pooled).cpu().numpy())
+        return np.concatenate(outs)
+    want_v, want_t = ref_preds(vdir, vnames), ref_preds(tdir, res["test_filenames"])
+    got_v = sc.transform(res["val_preds"].astype(np.float64))
+    assert np.abs(got_v - want_v).max() < 2e-3                                   # std units; f32 inverse_transform ulp = 0.0156 / 900
+    assert np.abs(sc.transform(res["test_preds"].astype(np.float64)) - want_t).max() < 2e-3
+    m = res["metrics"]
+    assert m["rmse"] == pytest.approx(np.sqrt(m["mse"]))
+    vcsv = pd.read_csv(sdir / "validation_predictions.csv")
+    assert list(vcsv.columns) == ["filename", "true_latitude", "true_longitude", "predicted_latitude", "predicted_longitude",
+                                  "error_latitude", "error_longitude"] and vcsv["filename"].tolist() == vnames
+    assert np.allclose(vcsv["predicted_latitude"], res["val_preds"][:, 0], atol=1e-6 * 3e5)
+    tcsv = pd.read_csv(sdir / "test_predictions_sorted.csv")
+    assert list(tcsv.columns) == ["filename", "predicted_latitude", "predicted_longitude"]
+    assert tcsv["filename"].tolist() == sorted(res["test_filenames"])
+    with open(sdir / "test_predictions_sorted.csv") as f:
+        assert all(len(x.split(".")[-1].strip()) == 6 for x in f.read().splitlines()[1].split(",")[1:])      # '%.6f'

@@ -13,6 +13,7 @@
 // grid, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 == an fmaf chain, cdna guide §3), partial slabs
 // summed in a fixed order by the epilogue kernel — bitwise reproducible run to run.
 #include <math.h>
+#include <stdlib.h>
 #include "vpr_common.h"
 #include "vpr_internal.h"
 
@@ -180,14 +181,17 @@ __global__ __launch_bounds__(256) void pose_linear_kernel(
 // Two-pass statistics in registers (mean, then centred sum of squares) like torch's LayerNorm.
 // ---------------------------------------------------------------------------------------------
 template <int VPL, bool BF16>
-__global__ __launch_bounds__(512) void ln_meanpool_head_kernel(
+__global__ __launch_bounds__(1024) void ln_meanpool_head_kernel(
     const void* __restrict__ xin, int T, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ pooled_out,
     const float* __restrict__ Wh, const float* __restrict__ bh, int n_out, int sincos_offset,
     float* __restrict__ out) {
   constexpr int H = VPL * 64;
   constexpr int NV = VPL / 4;
-  constexpr int NW = 8;            // 8 waves per image: 6-7 tokens per wave at T = 49 (4 waves: 14.3 us for 25.7 MB)
+  constexpr int NW = 16;           // 16 waves per image ...
+  constexpr int TB = VPL <= 16 ? 4 : 2;   // ... each with TB token rows requested before the first reduction: T = 49 is ONE
+                                   // memory round trip per wave, T = 144 three (round 1: 8 waves, one row ahead = 7 / 18
+                                   // dependent trips: 12.8 / 21.3 us for 25.7 / 75.5 MB)
   __shared__ float pool[NW][H];
   __shared__ float outs[8];
   const int b = blockIdx.x;
@@ -204,10 +208,8 @@ __global__ __launch_bounds__(512) void ln_meanpool_head_kernel(
       accp[c * 4 + e] = 0.f;
     }
 
-  // a wave walks its tokens (wave, wave+NW, ...) with the NEXT token's row already requested while the current
-  // one goes through its two reductions: one memory round trip per wave instead of one per token
   auto load_row = [&](int t, float (&xv)[VPL]) {
-    const int tc = t < T ? t : T - 1;
+    const int tc = t < T ? t : T - 1;                // clamped past the end: a harmless re-read of the last row
     if (BF16) {
       const uint16_t* row = reinterpret_cast<const uint16_t*>(xin) + ((long long)b * T + tc) * H;
 #pragma unroll
@@ -227,23 +229,27 @@ __global__ __launch_bounds__(512) void ln_meanpool_head_kernel(
       }
     }
   };
-  float xv[VPL], xn[VPL];
-  load_row(wave, xv);
-  for (int t = wave; t < T; t += NW) {
-    load_row(t + NW, xn);            // clamped past the end: a harmless re-read of the last row
-    float s = 0.f;
+  // token order per wave is fixed (wave, wave + NW, ...), and so is the order of its running sum: deterministic
+  for (int t0 = wave; t0 < T; t0 += NW * TB) {
+    float xv[TB][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s += xv[i];
-    const float mean = wave_sum(s) / (float)H;
-    float ss = 0.f;
+    for (int j = 0; j < TB; ++j) load_row(t0 + NW * j, xv[j]);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { const float d = xv[i] - mean; ss = fmaf(d, d, ss); }
-    const float var = wave_sum(ss) / (float)H;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int j = 0; j < TB; ++j) {
+      if (t0 + NW * j < T) {                         // wave-uniform
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) accp[i] += (xv[i] - mean) * rstd * gm[i] + bt[i];
+        for (int i = 0; i < VPL; ++i) s += xv[j][i];
+        const float mean = wave_sum(s) / (float)H;
+        float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) xv[i] = xn[i];
+        for (int i = 0; i < VPL; ++i) { const float d = xv[j][i] - mean; ss = fmaf(d, d, ss); }
+        const float var = wave_sum(ss) / (float)H;
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) accp[i] += (xv[j][i] - mean) * rstd * gm[i] + bt[i];
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < NV; ++c)
@@ -252,14 +258,16 @@ __global__ __launch_bounds__(512) void ln_meanpool_head_kernel(
   __syncthreads();
   // fixed-order cross-wave sum; thread h keeps pooled[h] for the head below
   for (int h = threadIdx.x; h < H; h += NW * 64) {
-    const float p = (((pool[0][h] + pool[1][h]) + (pool[2][h] + pool[3][h])) +
-                     ((pool[4][h] + pool[5][h]) + (pool[6][h] + pool[7][h]))) / (float)T;
+    float p = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 4) p += (pool[w][h] + pool[w + 1][h]) + (pool[w + 2][h] + pool[w + 3][h]);
+    p /= (float)T;
     pool[0][h] = p;
     if (pooled_out) pooled_out[(long long)b * H + h] = p;
   }
   __syncthreads();
   if (Wh == nullptr || n_out <= 0) return;
-  for (int o = wave; o < n_out; o += 8) {
+  for (int o = wave; o < n_out; o += NW) {
     float s = 0.f;
     for (int h = lane; h < H; h += 64) s = fmaf(pool[0][h], Wh[(long long)o * H + h], s);
     s = wave_sum(s);
@@ -396,6 +404,8 @@ static int pick_slices_split(int B, int D, int hidden) {
   if (ks > max_ks) ks = max_ks;
   if (ks > 32) ks = 32;
   if (ks < 1) ks = 1;
+  const char* e = getenv("VPR_POSE_KS");          // A/B switch (slices per tile), clamped to what the workspace query allows
+  if (e && atoi(e) >= 1 && atoi(e) <= 64 && atoi(e) <= (D / 32)) ks = atoi(e);
   return ks;
 }
 
@@ -452,10 +462,10 @@ static int launch_ln(const void* x, int bf16, int B, int T, const float* gamma, 
                       float* pooled, const float* Wh, const float* bh, int n_out, int so, float* out,
                       hipStream_t stream) {
   if (bf16)
-    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, true>), dim3(B), dim3(512), 0, stream, x, T, gamma, beta,
+    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, true>), dim3(B), dim3(1024), 0, stream, x, T, gamma, beta,
                        eps, pooled, Wh, bh, n_out, so, out));
   else
-    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, false>), dim3(B), dim3(512), 0, stream, x, T, gamma, beta,
+    VPR_TRY_LAUNCH(launch_kernel((ln_meanpool_head_kernel<VPL, false>), dim3(B), dim3(1024), 0, stream, x, T, gamma, beta,
                        eps, pooled, Wh, bh, n_out, so, out));
   return VPR_OK;
 }

@@ -123,3 +123,99 @@ def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, p
         if verbose:
             print("Saved predictions to preds.csv")
     return {"final_loss": final_loss, "preds": all_preds, "targets": all_targets, "filenames": filenames}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Swin-Base validation + test-set entry point: swin_transformer/val_and_test_swin_2.py
+IMAGE_EXTENSIONS = ["*.jpg", "*.jpeg", "*.png", "*.bmp", "*.gif", "*.JPEG"]        # :44
+
+
+def _loadable(path: str) -> bool:
+    """The reference's per-file check (CampusDataset :73-90 `img.verify()`, TestImageDataset :150-155 returning None
+    for the collate functions :179-195 to drop): a file that PIL cannot open is skipped with a message, not fatal."""
+    try:
+        with Image.open(path) as im:
+            im.verify()
+        return True
+    except Exception as e:                                   # FileNotFoundError, UnidentifiedImageError, OSError, ...
+        print(f"Warning: Skipping invalid/corrupt image file: {path} ({e})")
+        return False
+
+
+@torch.no_grad()
+def _predict_files(model, image_dir: str, filenames, prep, scaler, batch_size: int, dev) -> np.ndarray:
+    preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
+        preds_std[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(image_dir, names, dev)))
+    return scaler.inverse_transform(preds_std.cpu().numpy())
+
+
+@torch.no_grad()
+def validate_and_test_swin(model, val_csv_path: str, val_image_dir: str, test_image_dir: Optional[str] = None,
+                           save_dir: Optional[str] = None, *, checkpoint_path: Optional[str] = None,
+                           scaler: Optional[postproc.LatLonScaler] = None, image_size: int = 384, batch_size: int = 32,
+                           device: str = "cuda", verbose: bool = True) -> dict:
+    """`model`: a vpr_amd.modules.SwinMLPRegressionModel (reference class `SwinRegressionModel`, :164-177).
+    Validation split (:247-293): rows whose image is missing or unreadable are skipped with a warning, predictions are
+    de-normalised, MSE / RMSE / MAE / MAE-lat / MAE-lon are printed in the reference's format and
+    `validation_predictions.csv` is written ('%.6f').  Test split (:296-342, when `test_image_dir` exists): every image
+    file of IMAGE_EXTENSIONS in basename order, unreadable ones dropped, `test_predictions_sorted.csv` sorted by
+    filename.  Preprocessing = the HF Swin image processor the script builds (:199): bicubic resize to `image_size`
+    (384 for swin-base-patch4-window12-384, :39-40), /255, ImageNet mean/std — on the GPU, PIL-exact."""
+    import glob
+    dev = torch.device(device)
+    model = model.to(dev).eval()
+    if checkpoint_path:
+        load_reference_checkpoint(model, checkpoint_path)                         # bare state dict, :231
+    scaler = scaler or postproc.LatLonScaler.campus()
+    prep = ResizeNormalize(image_size, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
+    out = {}
+
+    val_df = pd.read_csv(val_csv_path)
+    keep = []
+    for i, f in enumerate(val_df["filename"]):
+        p = os.path.join(val_image_dir, f)
+        if not os.path.isfile(p):
+            print(f"Warning: Image file not found and skipped: {p}")              # :92
+        elif _loadable(p):
+            keep.append(i)
+    if not keep:
+        raise ValueError("No valid image files found for the provided validation dataframe and image directory.")   # :95
+    vdf = val_df.iloc[keep].reset_index(drop=True)
+    names = vdf["filename"].tolist()
+    preds = _predict_files(model, val_image_dir, names, prep, scaler, batch_size, dev)
+    targets = vdf[["latitude", "longitude"]].to_numpy(dtype=np.float32)           # the script's float32 target tensors (:120)
+    out.update(val_filenames=names, val_preds=preds, val_targets=targets, metrics=postproc.regression_metrics(preds, targets))
+    if verbose:
+        print("\n" + reports.format_metrics(preds, targets))
+        print("-" * 30)
+    if save_dir:
+        os.makedirs(save_dir, exist_ok=True)
+        path = os.path.join(save_dir, "validation_predictions.csv")              # :35
+        reports.write_validation_csv(path, names, targets, preds)
+        if verbose:
+            print(f"Successfully saved validation prediction results to: {path}")
+
+    if test_image_dir is None or not os.path.isdir(test_image_dir):
+        if verbose:
+            print(f"Warning: Test image directory not found: {test_image_dir}. Skipping test set prediction.")   # :23
+        return out
+    paths = []
+    for ext in IMAGE_EXTENSIONS:
+        paths.extend(glob.glob(os.path.join(test_image_dir, ext)))
+    paths.sort(key=lambda p: os.path.basename(p))                                 # :133
+    if not paths:
+        print(f"No image files ({', '.join(IMAGE_EXTENSIONS)}) found in {test_image_dir}")                       # :136
+        return out
+    tnames = [os.path.basename(p) for p in paths if _loadable(p)]                 # None items dropped by the collate (:189-191)
+    if not tnames:
+        print("No test predictions were made. Check test data directory and image files.")                       # :321
+        return out
+    tpreds = _predict_files(model, test_image_dir, tnames, prep, scaler, batch_size, dev)
+    out.update(test_filenames=tnames, test_preds=tpreds)
+    if save_dir:
+        path = os.path.join(save_dir, "test_predictions_sorted.csv")              # :36
+        reports.write_test_csv(path, tnames, tpreds)
+        if verbose:
+            print(f"Successfully saved sorted test prediction results to: {path}")
+    return out
