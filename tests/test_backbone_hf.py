@@ -12,6 +12,8 @@ Random-init HF weights -> key map (vpr_amd/checkpoint.py) -> same images -> same
 import copy
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -214,3 +216,56 @@ def test_tanh_gelu_deviation_at_descriptor_level(dev):
     print(f"\n[gelu] descriptor max|tanh - erf| = {dev_gelu:.3e}; bf16-vs-f32 backbone max diff = {noise:.3e}; min cosine {cos:.6f}")
     assert dev_gelu <= 1.5 * noise                     # the GELU form is inside the bf16 noise of the backbone
     assert cos > 0.999
+
+
+def test_angle_head_variants_keep_the_reference_state_dict_keys():
+    """§8 a-5: the gemini sin/cos heads.  Swin MLP variant: keys regressor.0/.3 with hidden = H/2
+    (swin_angle_finetuning_gemini.py:101-106); DINOv2 CLS variant: backbone.* + head.* (dino_v2_gemini.py:99-106), and a
+    checkpoint in the Hugging Face key layout (what AutoModel.from_pretrained produces) loads strictly."""
+    from transformers import SwinConfig, SwinModel
+    from vpr_amd import modules
+    sw = modules.SwinAngleRegressorSinCos(SwinModel(SwinConfig()))
+    keys = {k for k in sw.state_dict() if k.startswith("regressor.")}
+    assert keys == {"regressor.0.weight", "regressor.0.bias", "regressor.3.weight", "regressor.3.bias"}
+    assert tuple(sw.regressor[0].weight.shape) == (384, 768) and tuple(sw.regressor[3].weight.shape) == (2, 384)
+    hf = _hf_model(128, 2, 2, seed=7)
+    m = modules.DinoV2AngleRegressorSinCos(_ours(128, 2, 2))
+    ref_sd = {"backbone." + k: v for k, v in hf.state_dict().items()}
+    ref_sd.update({"head.weight": torch.randn(2, 128), "head.bias": torch.randn(2)})
+    res = m.load_state_dict(ref_sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(m.head.weight, ref_sd["head.weight"])
+    x = torch.randn(2, 3, 224, 224)
+    with torch.no_grad():
+        want = hf(pixel_values=x).last_hidden_state[:, 0]
+        got = m.backbone(x)[:, 0]
+    assert (want - got).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_dinov2_cls_sincos_model_on_gpu(dev):
+    """dino_v2_gemini.py:108-114 on the HIP path: CLS of the final-norm tokens -> head (vpr_pose_head, hidden = 0) ->
+    raw (sin, cos) -> degrees; against the same arithmetic in f32 torch on HF's Dinov2Model."""
+    from vpr_amd import modules, postproc
+    hf = _hf_model(384, 12, 6, seed=8).to(dev)
+    head = torch.nn.Linear(384, 2).to(dev)
+    m = modules.DinoV2AngleRegressorSinCos(_ours(384, 12, 6))
+    sd = {"backbone." + k: v for k, v in hf.state_dict().items()}
+    sd.update({"head." + k: v for k, v in head.state_dict().items()})
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.backbone.to(torch.bfloat16)
+    m.backbone.gelu = "erf"
+    m.backbone.fold_layerscale()
+    x = torch.randn(6, 3, 224, 224, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = head(hf(pixel_values=x.float()).last_hidden_state[:, 0])
+        hf16 = copy.deepcopy(hf).to(torch.bfloat16)
+        yard = head(hf16(pixel_values=x).last_hidden_state[:, 0].float())
+        out = m(x)
+    e_out, e_yard = (out - ref).abs().max().item(), (yard - ref).abs().max().item()
+    print(f"\n[cls-sincos] HIP path max err {e_out:.3e}, HF bf16 max err {e_yard:.3e}")
+    assert out.shape == (6, 2) and e_out < 2.0 * e_yard + 1e-3
+    deg = postproc.sincos_to_degrees(out.cpu().numpy())
+    want = (torch.rad2deg(torch.atan2(out[:, 0], out[:, 1])) % 360.0).cpu().numpy()      # prediction_to_angle_deg :135-141
+    assert np.allclose(deg, want, atol=1e-3)

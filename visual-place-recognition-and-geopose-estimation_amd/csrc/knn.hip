@@ -310,104 +310,109 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
   }
 }
 
-// 2a. level-0 select straight from the score matrix: grid (chunks, B), chunk = `ch` scores
-// (multiple of 1024, <= 8192).  Two streaming passes instead of holding the chunk in registers:
-//   pass 1  every thread finds the max (value, then lower index) of its strided elements with
-//           plain f32 compares (its scan order is index-ascending, so strict '>' keeps ties right);
-//   rank    T = the kp-th largest of the published maxes (64 quad maxes when kp <= 32, else the
-//           256 thread maxes) bounds the kp-th largest key of the chunk from below; keys are
-//           unique, so at most (elements per group)*(kp-1)+1 <= 4096 keys are >= T whatever the
-//           data — ties, sorted input, all-equal scores;
-//   pass 2  re-read the chunk (L2-hot) and append keys >= T to an LDS list (typically ~kp);
-//   order   each listed key counts the listed keys above it = its rank; ranks < kp are written.
+// 2a. level-0 select straight from the score matrix: grid (chunks, B), chunk = `ch` scores (multiple of 1024,
+// <= 8192).  The chunk is read ONCE: every thread requests its (up to) 8 float4 (32 scores, strided by 1024 so a wave
+// reads 1 KiB lines) before the first compare and keeps them in registers for both phases:
+//   max     the thread's best (value, then lower index) of its 32 scores, plain f32 compares in index-ascending
+//           order (strict '>' keeps ties right);
+//   rank    T = the kp-th largest of the 256 published thread maxes bounds the kp-th largest key of the chunk from
+//           below; keys are unique, so at most 32 (kp-1) + 1 keys are >= T whatever the data — ties, sorted input,
+//           all-equal scores: CAP = 1024 for kp <= 32 (k <= 16), 4096 otherwise;
+//   filter  keys >= T (from the registers) appended to an LDS list (typically ~kp of them);
+//   order   each listed key counts the listed keys above it = its rank; ranks < kp are written, rank-ordered.
+// Round 1 read the chunk twice with dependent loads (8 round trips per pass) under 35 KB of LDS (4 workgroups per CU):
+// 15.7 us at 100k rows, 117 us at 1M; this form needs 15 KB (kp <= 32) and one round trip.
+template <int CAP>
 __global__ __launch_bounds__(256) void knn_select_stream_kernel(
     const float* __restrict__ S, int N, long long ldS, int ch,
     float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk) {
-  __shared__ SelectSmem sm;
+  __shared__ unsigned long long tmax[256];
+  __shared__ unsigned long long wtop[4][128];
+  __shared__ unsigned long long cand[CAP];
+  __shared__ unsigned long long outk[128];
+  __shared__ unsigned long long thr;
+  __shared__ int cnt;
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* v = S + (long long)b * ldS;
   const int base = c * ch;
   const int len = min(ch, N - base);          // >= 1
+  float4 q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = tid * 4 + i * 1024;
+    // rows of S are padded to a multiple of 64 floats (ldS), so a float4 that starts inside the row stays inside it;
+    // positions past `len` are masked below
+    q[i] = p < len ? *reinterpret_cast<const float4*>(v + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float bv = -INFINITY;
   int bi = -1;
-  for (int p = tid * 4; p < len; p += 1024) {
-    if (p + 4 <= len) {
-      const float4 q = *reinterpret_cast<const float4*>(v + base + p);
-      if (q.x > bv || bi < 0) { bv = q.x; bi = base + p; }
-      if (q.y > bv) { bv = q.y; bi = base + p + 1; }
-      if (q.z > bv) { bv = q.z; bi = base + p + 2; }
-      if (q.w > bv) { bv = q.w; bi = base + p + 3; }
-    } else {
-      for (int e = p; e < len; ++e) {
-        const float x = v[base + e];
-        if (x > bv || bi < 0) { bv = x; bi = base + e; }
-      }
-    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = tid * 4 + i * 1024;
+    const float qq[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (p + e < len && (qq[e] > bv || bi < 0)) { bv = qq[e]; bi = base + p + e; }
   }
-  unsigned long long best = bi >= 0 ? make_key(bv, bi) : KEY_DEAD;
-  if (tid == 0) { sm.thr = 1ull; sm.cnt = 0; }
-  if (tid < kp) sm.outk[tid] = KEY_DEAD;
-  if (kp <= 32) {
-    unsigned long long o = dpp_u64<0xB1>(best);
-    best = o > best ? o : best;
-    o = dpp_u64<0x4E>(best);
-    best = o > best ? o : best;
-    if ((tid & 3) == 0) sm.tmax[tid >> 2] = best;
-    __syncthreads();
-    if (tid < 64) {
-      const unsigned long long mine = sm.tmax[tid];
-      int rank = 0;
-      for (int s = 0; s < 64; s += 2) {
-        const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
-        rank += (t2.x > mine ? 1 : 0) + (t2.y > mine ? 1 : 0);
+  const unsigned long long best = bi >= 0 ? make_key(bv, bi) : KEY_DEAD;
+  if (tid == 0) { thr = 1ull; cnt = 0; }
+  if (tid < kp) outk[tid] = KEY_DEAD;
+  for (int i = tid; i < 4 * 128; i += 256) wtop[i >> 7][i & 127] = KEY_DEAD;
+  tmax[tid] = best;
+  __syncthreads();
+  // kp-th largest of the 256 thread maxes without the 256 x 256 all-pairs ranking (VALU-bound: 100 us at 1M rows):
+  // rank inside the own wave (64 broadcast reads), the top kp of every wave go to a sorted list, and the global rank
+  // of a listed key = own rank + binary searches in the other three lists.
+  const int wv = tid >> 6;
+  int wr = 0;
+  for (int s = 0; s < 64; s += 2) {
+    const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&tmax[wv * 64 + s]);
+    wr += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
+  }
+  const bool listed = best != KEY_DEAD && wr < kp;
+  if (listed) wtop[wv][wr] = best;
+  __syncthreads();
+  if (listed) {
+    int gr = wr;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (w2 == wv) continue;
+      int lo = 0, hi = kp;                      // descending list, KEY_DEAD (= 0) padding at the end
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (wtop[w2][mid] > best) lo = mid + 1; else hi = mid;
       }
-      if (rank == kp - 1 && mine != KEY_DEAD) sm.thr = mine;   // unique keys: one writer
+      gr += lo;
     }
-  } else {
-    sm.tmax[tid] = best;
-    __syncthreads();
-    int rank = 0;
-    for (int s = 0; s < 256; s += 2) {
-      const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(&sm.tmax[s]);
-      rank += (t2.x > best ? 1 : 0) + (t2.y > best ? 1 : 0);
-    }
-    if (rank == kp - 1 && best != KEY_DEAD) sm.thr = best;
+    if (gr == kp - 1) thr = best;               // unique keys: one writer
   }
   __syncthreads();
-  const unsigned long long T = sm.thr;
+  const unsigned long long T = thr;
   // key >= T  <=>  value > Tv, or value == Tv and index <= Ti  (T == 1: no threshold, take all)
   const bool all = T == 1ull;
   const float Tv = all ? -INFINITY : key_val(T);
   const int Ti = all ? 0x7fffffff : key_idx(T);
-  for (int p = tid * 4; p < len; p += 1024) {
-    if (p + 4 <= len) {
-      const float4 q = *reinterpret_cast<const float4*>(v + base + p);
-      const float qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = qq[e];
-        if (x > Tv || (x == Tv && base + p + e <= Ti) || all)
-          sm.cand[atomicAdd(&sm.cnt, 1)] = make_key(x, base + p + e);
-      }
-    } else {
-      for (int e = p; e < len; ++e) {
-        const float x = v[base + e];
-        if (x > Tv || (x == Tv && base + e <= Ti) || all)
-          sm.cand[atomicAdd(&sm.cnt, 1)] = make_key(x, base + e);
-      }
+  for (int i = 0; i < 8; ++i) {
+    const int p = tid * 4 + i * 1024;
+    const float qq[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = qq[e];
+      if (p + e < len && (x > Tv || (x == Tv && base + p + e <= Ti) || all))
+        cand[atomicAdd(&cnt, 1)] = make_key(x, base + p + e);
     }
   }
   __syncthreads();
-  const int cn = sm.cnt;
+  const int cn = cnt;
   for (int ci = tid; ci < cn; ci += 256) {
-    const unsigned long long mine = sm.cand[ci];
+    const unsigned long long mine = cand[ci];
     int r = 0;
-    for (int cj = 0; cj < cn; ++cj) r += sm.cand[cj] > mine ? 1 : 0;
-    if (r < kp) sm.outk[r] = mine;
+    for (int cj = 0; cj < cn; ++cj) r += cand[cj] > mine ? 1 : 0;
+    if (r < kp) outk[r] = mine;
   }
   __syncthreads();
   if (tid < kp) {
-    const unsigned long long k = sm.outk[tid];
+    const unsigned long long k = outk[tid];
     const long long o = ((long long)b * nchunk + c) * kp + tid;
     out_val[o] = k == KEY_DEAD ? -INFINITY : key_val(k);
     out_idx[o] = k == KEY_DEAD ? -1 : key_idx(k);
@@ -1008,8 +1013,11 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
     if (lev > 0 && L <= SEL_CAP && (size_t)rb <= 24 * 1024) break;
     float* ov = reinterpret_cast<float*>(w + p.off_cv[lev & 1]);
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
-    if (lev == 0)
-      VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel, dim3(p.nchunk[0], B), dim3(256), 0, stream,
+    if (lev == 0 && p.kp <= 32)
+      VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel<1024>, dim3(p.nchunk[0], B), dim3(256), 0, stream,
+                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0]));
+    else if (lev == 0)
+      VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel<4096>, dim3(p.nchunk[0], B), dim3(256), 0, stream,
                                    cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0]));
     else
       VPR_TRY_LAUNCH(launch_kernel(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,

@@ -12,6 +12,10 @@ so its checkpoints load and its evaluation loops run unchanged:
         .regressor = Linear(hidden,512)-ReLU-Dropout-Linear(512,2); keys regressor.0.*, regressor.3.*
   SwinSinCosRegressionModel(backbone)   angle_prediction/swin/swin_angle_finetuning_sin_cos.py:52-62
         Linear(hidden,2) + F.normalize(eps=1e-6) -> unit [sin, cos]
+  SwinAngleRegressorSinCos(backbone)    angle_prediction/swin/swin_angle_finetuning_gemini.py:92-128
+        Linear(H,H/2)-ReLU-Dropout-Linear(H/2,2) -> raw [sin, cos]; keys regressor.0.*, regressor.3.*
+  DinoV2AngleRegressorSinCos(backbone)  angle_prediction/dinov2salad/dino_v2_gemini.py:99-114
+        DINOv2 CLS -> Dropout -> head = Linear(hidden,2) -> raw [sin, cos]; keys backbone.* (HF layout accepted), head.*
 The reference builds its backbones with from_pretrained(NAME) inside __init__ (a network fetch);
 here the backbone object is passed in.  `DinoV2Salad` is the `feature_extractor`:
 DINOv2 (PyTorch) + SaladAggregator (HIP), keys `aggregator.*` as in serizba/salad.
@@ -166,6 +170,37 @@ class SwinMLPRegressionModel(nn.Module):
         h, ln = _swin_hidden(self.backbone, pixel_values)
         pooled, _ = ops.ln_meanpool_head(h, ln.weight.float().contiguous(), ln.bias.float().contiguous(), ln.eps)
         return ops.pose_head(pooled, *_mlp_head_args(self.regressor))
+
+
+class SwinAngleRegressorSinCos(SwinMLPRegressionModel):
+    """angle_prediction/swin/swin_angle_finetuning_gemini.py:92-128 (there also called `SwinRegressionModel`; renamed
+    because swin_validation.py's class owns that name here): Swin pooler -> Linear(H, H/2) -> ReLU -> Dropout ->
+    Linear(H/2, 2) = raw (sin, cos), NOT unit-normalised (its loss is an MSE on the pair); decoded with
+    postproc.sincos_to_degrees (:131-136).  Keys regressor.0.*, regressor.3.*."""
+
+    def __init__(self, backbone: nn.Module, dropout_rate: float = 0.0):
+        super().__init__(backbone, dropout_rate, hidden=backbone.config.hidden_size // 2)
+
+
+class DinoV2AngleRegressorSinCos(nn.Module):
+    """angle_prediction/dinov2salad/dino_v2_gemini.py:99-114: DINOv2 CLS token -> Dropout -> `head` = Linear(hidden, 2) =
+    raw (sin, cos); decoded by prediction_to_angle_deg (:135-141) = postproc.sincos_to_degrees.  The reference builds
+    the backbone with AutoModel.from_pretrained("facebook/dinov2-base") (a fetch); here a vpr_amd.backbone.DinoV2 is
+    passed in, and its load hook takes the Hugging Face key layout the reference's checkpoints carry
+    (`backbone.embeddings.*`, `backbone.encoder.layer.N.*`), so `load_state_dict(torch.load(best_model.pth))` works
+    unchanged.  Keys: backbone.*, head.weight [2, hidden], head.bias [2]."""
+
+    def __init__(self, backbone: DinoV2, dropout_rate: float = 0.1):
+        super().__init__()
+        self.backbone = backbone
+        self.dropout = nn.Dropout(dropout_rate)                # eval: identity
+        self.head = nn.Linear(backbone.embed_dim, 2)
+
+    @torch.no_grad()
+    def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        t = self.backbone(pixel_values, split=True)            # final-norm tokens; the cls rows are a contiguous [B, C]
+        pooled = t.cls.float().contiguous()
+        return ops.pose_head(pooled, None, None, self.head.weight.float().contiguous(), self.head.bias.float().contiguous())
 
 
 class FusedGeoPoseHead(nn.Module):
