@@ -61,6 +61,13 @@ def test_bench_force_dist_runs_the_collectives_on_rccl(dev):
     d = _json_line(p.stdout)
     assert d["dist"] == {"process_group": "nccl", "collectives_in_step": True}
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["recall_at_1"] == 1.0 and d["uncertified_queries"] == 0
+    # two batches in flight on two streams, each step with its collectives on the one process group
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline",
+                        "--no-kernel-rows", "--in-flight", "2"] + SMALL + ["--steps", "6"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=dict(env, MASTER_PORT=str(port + 1)))
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _json_line(p.stdout)
+    assert d["config"]["batches_in_flight"] == 2 and d["dist"]["collectives_in_step"] and d["recall_at_1"] == 1.0
 
 
 def test_bench_fp8_gallery(dev):

@@ -95,7 +95,8 @@ PROTOTYPES = {
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libvpr_amd.so")
+    """The in-tree library; VPR_AMD_LIBRARY points an A/B run at another build of it (scripts/ab_libs.sh)."""
+    return os.environ.get("VPR_AMD_LIBRARY") or os.path.join(_HERE, "libvpr_amd.so")
 
 
 def lib() -> ctypes.CDLL:
