@@ -35,6 +35,22 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+class _StdoutToStderr:
+    """File descriptor 1 -> 2 for the duration of the block.  RCCL 2.26 prints a version banner ("RCCL version : ...",
+    five lines) to STDOUT when its first communicator is created; this run's stdout is reserved for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def make_gallery_shard(rows: int, seed: int, dev) -> torch.Tensor:
     g = torch.Generator(device=dev).manual_seed(seed)
     out = torch.empty((rows, D_DESC), dtype=torch.bfloat16, device=dev)
@@ -174,6 +190,36 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
     return rows
 
 
+def config1_swin_tiny(dev) -> dict:
+    """BASELINE config 1 (the reference's own CPU-runnable case, swin_transformer/swin_validation.py plumbing):
+    Swin-Tiny 224x224 -> (lat, lon), batch 8.  CPU: HF SwinModel(SwinConfig()) (random init, seed 0) + Linear(768, 2) in
+    f32 on the host cores, median of 10 calls after 3 warm-ups.  GPU: the same weights through
+    vpr_amd.modules.SwinRegressionModel (PyTorch-ROCm backbone + vpr_ln_meanpool_head)."""
+    import statistics
+    from transformers import SwinConfig, SwinModel
+    from vpr_amd.modules import SwinRegressionModel
+    threads = min(os.cpu_count(), 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    backbone = SwinModel(SwinConfig()).eval()
+    model = SwinRegressionModel(backbone).eval()
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    ts = []
+    with torch.no_grad():
+        for i in range(13):
+            t0 = time.perf_counter()
+            pooled = backbone(pixel_values=x).pooler_output
+            model.regressor(pooled)
+            if i >= 3:
+                ts.append(time.perf_counter() - t0)
+    cpu = 8 / statistics.median(ts)
+    gm = model.to(dev)
+    xd = x.to(dev)
+    ms = _avg_ms(lambda: gm(xd), n=10, warm=3)
+    return {"workload": "Swin-Tiny 224 (random init) + Linear(768,2), batch 8, f32", "cpu_images_per_s": cpu, "cpu_threads": threads,
+            "gpu_images_per_s": 8 / (ms * 1e-3), "gpu_ms_per_batch": ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,10 +260,13 @@ def main():
     if use_dist:
         if "MASTER_ADDR" not in os.environ:                            # bare `python bench.py --force-dist`
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)     # RCCL over xGMI
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+        with _StdoutToStderr():
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)     # RCCL over xGMI
+            else:
+                dist.init_process_group(a.backend, rank=rank, world_size=world)
+            dist.barrier()                     # communicator creation (and RCCL's banner) happens here at the latest
+            torch.cuda.synchronize()
 
     from vpr_amd import _lib, ops
     _lib.lib()
@@ -379,6 +428,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             sample = shard.cpu()                                # whole gallery: the sample is one full step
             res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images.cpu(), sample, a.gallery, a.k)
+            res["cpu_baseline"]["config1_swin_tiny"] = config1_swin_tiny(dev)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

@@ -37,6 +37,8 @@ def test_bench_single_rank_contract(dev):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "images" in c["sample"]
+    c1 = c["config1_swin_tiny"]                               # BASELINE config 1: the reference's CPU-runnable case
+    assert c1["cpu_images_per_s"] > 0 and c1["gpu_images_per_s"] > c1["cpu_images_per_s"]
     assert d["recall_at_1"] == 1.0 and "workload" in d["config"]
     assert r["kernel"] == "vpr::knn_scores_kernel<false, 208, 2, 4>" and r["traffic"] is None   # not the profiled workload
     assert d["uncertified_queries"] == 0
@@ -59,6 +61,7 @@ def test_bench_force_dist_runs_the_collectives_on_rccl(dev):
                         "--no-kernel-rows"] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = _json_line(p.stdout)
+    assert p.stdout.strip().startswith("{") and len(p.stdout.strip().splitlines()) == 1      # RCCL's banner kept off stdout
     assert d["dist"] == {"process_group": "nccl", "collectives_in_step": True}
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["recall_at_1"] == 1.0 and d["uncertified_queries"] == 0
     # two batches in flight on two streams, each step with its collectives on the one process group
