@@ -22,6 +22,8 @@ import time
 # runtime, ~300 kernels per step: 11.74 -> 11.41 ms per step (same box, twice).  Read by the HIP runtime when it
 # initialises, so it has to be in the environment before the first HIP call; an explicit setting wins.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# dmabuf IPC (the only form this pool's driver supports): RCCL across processes fails with hipIpcGetMemHandle without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
