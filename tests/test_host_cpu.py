@@ -299,3 +299,46 @@ def test_forced_collectives_single_rank_gloo_and_fp8_shard_helper(tmp_path):
         assert torch.equal(i8, i8r) and torch.equal(v8, v8r)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("unit", [True, False])
+def test_finetune_angle_head_matches_a_reference_style_loop(unit):
+    """§8f-4 widened to the sin/cos heads: same loss (acos angular loss on unit vectors, swin_angle_finetuning_sin_cos.py
+    :65-69, or MSE on the raw pair, swin_angle_finetuning_gemini.py:183), optimiser, scheduler and batch order as a
+    loop written the reference's way -> same per-epoch losses; the error metric falls."""
+    from vpr_amd import finetune
+    torch.manual_seed(1)
+    n, H = 144, 64
+    feats = torch.randn(n, H)
+    ang = (torch.atan2(feats[:, 0], feats[:, 1]) * 180 / np.pi) % 360                  # learnable from the features
+    head = nn.Linear(H, 2)
+    ref = nn.Linear(H, 2)
+    ref.load_state_dict(head.state_dict())
+    out = finetune.finetune_angle_head(head, feats, ang.numpy(), unit=unit, epochs=4, batch_size=48, lr=5e-2, seed=9,
+                                       val=(feats[:32], ang[:32].numpy()), log=lambda s: None)
+    a = torch.deg2rad(ang)
+    tgt = torch.stack([torch.sin(a), torch.cos(a)], 1)                                  # [sin, cos] (:47)
+    opt = torch.optim.AdamW(ref.parameters(), lr=5e-2)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+    g = torch.Generator().manual_seed(9)
+    losses = []
+    for epoch in range(4):
+        perm = torch.randperm(n, generator=g)
+        tot = 0.0
+        for lo in range(0, n, 48):
+            idx = perm[lo:lo + 48]
+            p = ref(feats[idx])
+            if unit:
+                p = torch.nn.functional.normalize(p, dim=1, p=2, eps=1e-6)
+                cs = torch.clamp((p * tgt[idx]).sum(dim=1), -0.999999, 0.999999)
+                loss = torch.mean(torch.rad2deg(torch.acos(cs)))
+            else:
+                loss = nn.functional.mse_loss(p, tgt[idx])
+            opt.zero_grad(); loss.backward(); opt.step()
+            tot += float(loss.detach())
+        sched.step()
+        losses.append(tot / 3)
+    got = [h["train_loss"] for h in out["history"]]
+    assert np.allclose(got, losses, rtol=1e-5, atol=1e-6), (got, losses)
+    assert out["history"][-1]["val_maae"] < out["history"][0]["val_maae"]
+    assert torch.allclose(head.weight, ref.weight, atol=1e-6)

@@ -982,6 +982,11 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   return VPR_OK;
 }
 
+// Default norm bounds of the unchecked entry points: L2-normalised descriptors.  A bf16-rounded unit vector has norm
+// within 2^-9 of 1; an e4m3 row (3 mantissa bits, scale = max/448) within 2^-4.
+constexpr float NORM_BOUND_BF16 = 1.002f;
+constexpr float NORM_BOUND_FP8 = 1.0625f;
+
 // Relative bound of |MFMA score - exact score| / (|q| |g|): D f32 additions of exact products in any order
 // (gamma_D = D 2^-24 to first order; 1.1 covers the higher-order terms, the final f32 rounding of the exact score
 // and the two scale multiplications of the fp8 path), times the caller's bound on the gallery row norms.
@@ -991,7 +996,7 @@ static float knn_err_rel(int D, float gallery_norm_bound) {
 
 int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
                int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream,
-               float gallery_norm_bound = 1.0f, int32_t* status = nullptr, int32_t* uncertified = nullptr) {
+               float gallery_norm_bound = NORM_BOUND_BF16, int32_t* status = nullptr, int32_t* uncertified = nullptr) {
   if (!(gallery_norm_bound > 0.f)) return VPR_ERR_INVALID_ARG;
   const float err_rel = knn_err_rel(D, gallery_norm_bound);
   KnnPlan p;
@@ -1145,11 +1150,6 @@ static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int in
   return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified);
 }
-
-// Default norm bounds of the unchecked entry points: L2-normalised descriptors.  A bf16-rounded unit vector has norm
-// within 2^-9 of 1; an e4m3 row (3 mantissa bits, scale = max/448) within 2^-4.
-constexpr float NORM_BOUND_BF16 = 1.002f;
-constexpr float NORM_BOUND_FP8 = 1.0625f;
 
 extern "C" int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
                             int index_base, float* out_val, int32_t* out_idx, void* workspace,

@@ -61,7 +61,7 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
             opt.zero_grad()
             loss.backward()
             opt.step()
-            total += float(loss)
+            total += float(loss.detach())
             nb += 1
         rec = {"epoch": epoch, "train_loss": total / max(nb, 1)}
         if val is not None:
@@ -79,3 +79,70 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
     for p in head.parameters():
         p.requires_grad_(False)
     return {"scaler": scaler, "history": history}
+
+
+# ------------------------------------------------------------------------------------- angle heads
+def angle_targets(angles_deg) -> torch.Tensor:
+    """[N] degrees -> [N, 2] = [sin, cos] (the Swin / DINOv2 angle scripts' order: swin_angle_finetuning_sin_cos.py:47)."""
+    a = torch.deg2rad(torch.as_tensor(np.asarray(angles_deg), dtype=torch.float32))
+    return torch.stack([torch.sin(a), torch.cos(a)], dim=1)
+
+
+def angular_loss(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """swin_angle_finetuning_sin_cos.py:65-69: mean angle (degrees) between unit vectors, cosine clamped to +-0.999999."""
+    cosine_sim = torch.clamp((preds * targets).sum(dim=1), -0.999999, 0.999999)
+    return torch.mean(torch.rad2deg(torch.acos(cosine_sim)))
+
+
+def angle_error_deg(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """compute_angle_error, :72-76: mean min(d, 360 - d) of the atan2-decoded angles."""
+    diff = torch.rad2deg(torch.abs(torch.atan2(preds[:, 0], preds[:, 1]) - torch.atan2(targets[:, 0], targets[:, 1]))) % 360
+    return torch.mean(torch.minimum(diff, 360 - diff))
+
+
+def finetune_angle_head(head: nn.Module, features: torch.Tensor, angles_deg, *, unit: bool = True, epochs: int = 20,
+                        batch_size: int = 48, lr: float = 1e-5, cosine_t_max: Optional[int] = 10,
+                        val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print) -> dict:
+    """Head-only training of a sin/cos angle head on cached pooled features (Swin pooler output / DINOv2 CLS token,
+    computed once by the HIP path: ops.ln_meanpool_head(..., want_pooled=True) / backbone(x, split=True).cls).
+      unit=True   swin_angle_finetuning_sin_cos.py: F.normalize(head(x), eps=1e-6), angular_loss, AdamW(1e-5) with
+                  CosineAnnealingLR(T_max=10) stepped per epoch (:92-93, :119), batches of 48 (:87);
+      unit=False  swin_angle_finetuning_gemini.py / dino_v2_gemini.py: raw (sin, cos), nn.MSELoss (:183).
+    The backbone stays frozen (the reference fine-tunes it as well: out of scope); `head` is the model's
+    `regressor` / `head` sub-module, so the result saves under the reference's state-dict keys."""
+    dev = features.device
+    y = angle_targets(angles_deg).to(dev)
+    head = head.to(dev).float()
+    for p in head.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.AdamW(head.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cosine_t_max) if cosine_t_max else None
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    n = features.shape[0]
+    fwd = (lambda x: torch.nn.functional.normalize(head(x), dim=1, p=2, eps=1e-6)) if unit else head
+    loss_fn = angular_loss if unit else nn.functional.mse_loss
+    history = []
+    for epoch in range(epochs):
+        head.train()
+        perm = torch.randperm(n, generator=g).to(dev)
+        total, nb = 0.0, 0
+        for lo in range(0, n, batch_size):
+            idx = perm[lo:lo + batch_size]
+            loss = loss_fn(fwd(features[idx]), y[idx])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            total += float(loss.detach())
+            nb += 1
+        if sched is not None:
+            sched.step()
+        rec = {"epoch": epoch, "train_loss": total / max(nb, 1)}
+        if val is not None:
+            head.eval()
+            with torch.no_grad():
+                rec["val_maae"] = float(angle_error_deg(fwd(val[0]), angle_targets(val[1]).to(dev)))
+        history.append(rec)
+        log(f"Epoch {epoch + 1} | Train Loss: {rec['train_loss']:.2f}" + (f" | Val Error: {rec['val_maae']:.2f}" if val else ""))
+    for p in head.parameters():
+        p.requires_grad_(False)
+    return {"history": history}
