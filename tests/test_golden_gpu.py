@@ -170,13 +170,22 @@ def test_calculate_validation_scores_end_to_end(dev, tmp_path):
     base = modules.DinoV2Salad("vit_small")
     head_src = modules.DINOv2RegressionModel(torch.nn.Identity())
     ck = tmp_path / "checkpoint_49_.pth"
-    sd = {("feature_extractor." + k): v for k, v in base.state_dict().items()}
+    # the checkpoint as the reference writes it (dinov2salad_finetuning.py:130): hub key names under feature_extractor.
+    # (backbone.model.blocks.N.attn.qkv, ls1.gamma, patch_embed.proj, mask_token) — the 16x16 grid is kept here so that
+    # the stage-by-stage comparison below uses the very same position embedding
+    from test_backbone_hf import _hub_named
+    sd = _hub_named({k: v for k, v in base.backbone.state_dict().items()}, "feature_extractor.backbone.model.", side_old=16)
+    sd["feature_extractor.backbone.model.pos_embed"] = base.backbone.pos_embed.detach().clone()
+    sd.update({("feature_extractor.aggregator." + k): v for k, v in base.aggregator.state_dict().items()})
     sd.update(head_src.state_dict())
     torch.save({"epoch": 49, "model_state_dict": sd}, ck)
-    res = evaluate.calculate_validation_scores(str(ck), str(csv), str(img_dir), base_model=base, batch_size=3, verbose=False)
+    fresh = modules.DinoV2Salad("vit_small")                       # different random init: the load must replace all of it
+    res = evaluate.calculate_validation_scores(str(ck), str(csv), str(img_dir), base_model=fresh, batch_size=3, verbose=False)
     assert res["preds"].shape == (7, 2) and res["filenames"] == names            # the missing file is dropped
-    # the same stages one by one
+    # the same stages one by one, on the model the checkpoint was written from
     base = base.to(dev).to(torch.bfloat16).eval()
+    base.backbone.gelu = "erf"                                     # what the entry point selects for reference checkpoints
+    base.backbone.fold_layerscale()                                # same order as the entry point: bf16 weights, then fold
     prep = ResizeNormalize(224, "bilinear", (0.5,) * 3, (0.5,) * 3, torch.bfloat16)
     want = []
     for n in names:
