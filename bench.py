@@ -288,6 +288,7 @@ def main():
     ext.backbone.fuse_ln_cls = a.fuse_ln_cls
     ext.backbone.cls_after_gemm = not a.cls_before_gemm
     ext.backbone.cls_side_chain = not a.no_side_chain
+    ext.backbone.auto_fold = not a.no_fold
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block
     pos = nn.Sequential(nn.Linear(D_DESC, 512), nn.ReLU(), nn.Linear(512, 2))

@@ -269,3 +269,21 @@ def test_dinov2_cls_sincos_model_on_gpu(dev):
     deg = postproc.sincos_to_degrees(out.cpu().numpy())
     want = (torch.rad2deg(torch.atan2(out[:, 0], out[:, 1])) % 360.0).cpu().numpy()      # prediction_to_angle_deg :135-141
     assert np.allclose(deg, want, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_forward_after_a_load_refolds_and_takes_the_hip_path(dev):
+    """A load un-folds LayerScale; the next bf16 GPU forward folds again by itself (auto_fold), so a freshly loaded
+    checkpoint runs the HIP backbone path — and computes the loaded function (against HF f32)."""
+    hf = _hf_model(384, 12, 6, seed=11).to(dev)
+    m = _ours(384, 12, 6).to(dev).to(torch.bfloat16).eval()
+    m.fold_layerscale()                                        # folded with its random init ...
+    m.load_state_dict(hf.state_dict())                         # ... then a checkpoint arrives
+    assert not any(b.folded for b in m.blocks)
+    x = torch.randn(2, 3, 224, 224, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        out = m(x).float()
+        ref = hf(pixel_values=x.float()).last_hidden_state
+    assert all(b.folded for b in m.blocks) and m._hip_split_ok(x)
+    rms = lambda d: d.pow(2).mean().sqrt().item()
+    assert rms(out - ref) < 0.02 * rms(ref)

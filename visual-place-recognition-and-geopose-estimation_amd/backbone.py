@@ -147,6 +147,8 @@ class DinoV2(nn.Module):
     def forward(self, x: torch.Tensor, split: bool = False):
         """x [B,3,H,W] -> final-norm tokens [B, 1+n, C] (cls first), contiguous; with split=True a
         SplitTokens(patch [B,n,C], cls [B,C]) pair (what the HIP path computes in; no copy)."""
+        if self.auto_fold and x.is_cuda and x.dtype == torch.bfloat16 and not all(b.folded for b in self.blocks):
+            self.fold_layerscale()      # inference-only module: a load un-folds (Block._load_from_state_dict), the next GPU forward re-folds
         if self._hip_split_ok(x):
             st = self._forward_hip_split(x)
             return st if split else st.joined()
@@ -180,6 +182,8 @@ class DinoV2(nn.Module):
     def _skinny_gelu_mode(self) -> int:
         return 1 if self.gelu == "tanh" else 4
 
+    auto_fold = True        # fold LayerScale at the first bf16 GPU forward after a load, so a freshly loaded checkpoint never
+                            # lands on the slow PyTorch block loop by accident (bench.py --no-fold turns it off for the A/B)
     hip_split = True
     cls_after_gemm = True
     fuse_ln_cls = False     # measured: 11.17/11.23 vs 11.22/11.26 ms per step — within noise, so the simpler path is the default
