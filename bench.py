@@ -360,13 +360,16 @@ def main():
     score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq).decode()
     pmc = os.path.join(ROOT, "profiles", "r02_knn_pmc.json")
     if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64 and a.knn_dtype == "bf16":
-        sys.path.insert(0, os.path.join(ROOT, "scripts"))
-        from pmc_summary import kernel_source_sha16
-        with open(pmc) as f:
-            pj = json.load(f)
-        if pj.get("source_sha16") == kernel_source_sha16(ROOT) and score_kernel in pj.get("kernels", {}):
-            traffic = pj["kernels"][score_kernel]["hbm_bytes_per_launch"]
-            traffic_source = f"profiles/r02_knn_pmc.json (source_sha16 {pj['source_sha16']}, {score_kernel})"
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from pmc_summary import kernel_source_sha16
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("source_sha16") == kernel_source_sha16(ROOT) and score_kernel in pj.get("kernels", {}):
+                traffic = pj["kernels"][score_kernel]["hbm_bytes_per_launch"]
+                traffic_source = f"profiles/r02_knn_pmc.json (source_sha16 {pj['source_sha16']}, {score_kernel})"
+        except Exception:                                       # noqa: BLE001  a broken summary only costs the traffic figure
+            traffic, traffic_source = None, None
 
     if bq <= 64 or a.knn_dtype == "fp8":
         roofline = {"bound": "hbm", "kernel": score_kernel if a.knn_dtype == "bf16" else f"vpr_knn_topk_fp8 (quantise queries + {score_kernel} + select)",
@@ -427,11 +430,17 @@ def main():
             "dist": {"process_group": (a.backend if use_dist else None), "collectives_in_step": gallery.collective},
         }
         if world == 1 and not a.no_kernel_rows:
-            res["kernels"] = kernel_rows(dev, ext, head, images, shard if a.knn_dtype == "bf16" else None, a)
+            try:                                                # auxiliary rows never cost the run its headline line
+                res["kernels"] = kernel_rows(dev, ext, head, images, shard if a.knn_dtype == "bf16" else None, a)
+            except Exception as e:                              # noqa: BLE001
+                res["kernels"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             sample = shard.cpu()                                # whole gallery: the sample is one full step
             res["cpu_baseline"] = cpu_baseline(ext_state, a.arch, head_cpu, images.cpu(), sample, a.gallery, a.k)
-            res["cpu_baseline"]["config1_swin_tiny"] = config1_swin_tiny(dev)
+            try:
+                res["cpu_baseline"]["config1_swin_tiny"] = config1_swin_tiny(dev)
+            except Exception as e:                              # noqa: BLE001  (e.g. transformers missing on the box)
+                res["cpu_baseline"]["config1_swin_tiny"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
