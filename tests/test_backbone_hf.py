@@ -158,12 +158,13 @@ def test_unknown_or_register_token_keys_are_refused():
 
 # --------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("gelu", ["tanh", "erf"])
-def test_hip_backbone_matches_hf_dinov2model_on_gpu(dev, gelu):
+@pytest.mark.parametrize("shape,gelu", [((384, 12, 6), "tanh"), ((384, 12, 6), "erf"),
+                                        ((1024, 24, 16), "tanh")])     # ViT-L/14: the benchmark's architecture
+def test_hip_backbone_matches_hf_dinov2model_on_gpu(dev, shape, gelu):
     """bf16 HIP path (split rows, side-stream cls chain, patchify embedding, fused kernels) against HF's f32
     forward of the same weights; yardstick = HF's own bf16 forward against its f32 forward."""
-    hf = _hf_model(384, 12, 6, seed=3).to(dev)
-    m = _ours(384, 12, 6)
+    hf = _hf_model(*shape, seed=3, layerscale=0.3 if shape[1] == 12 else 0.15).to(dev)
+    m = _ours(*shape)
     m.load_state_dict(hf.state_dict())
     m = m.to(dev).to(torch.bfloat16).eval()
     m.gelu = gelu
@@ -178,7 +179,7 @@ def test_hip_backbone_matches_hf_dinov2model_on_gpu(dev, gelu):
         out = m(xb).float()
     rms = lambda d: d.pow(2).mean().sqrt().item()
     e_out, e_yard, scale = rms(out - ref), rms(yard - ref), rms(ref)
-    print(f"\n[hf-pin] gelu={gelu}: HIP path rms err {e_out:.3e}, HF bf16 rms err {e_yard:.3e}, token rms {scale:.3f}")
+    print(f"\n[hf-pin] {shape} gelu={gelu}: HIP path rms err {e_out:.3e}, HF bf16 rms err {e_yard:.3e}, token rms {scale:.3f}")
     assert e_out < 1.15 * e_yard and e_out < 0.02 * scale, (e_out, e_yard, scale)
     assert (out - ref).abs().max().item() < 2.0 * (yard - ref).abs().max().item()
 
