@@ -65,7 +65,47 @@ def collect(directory: str, counter: str, prefix: str):
     return out
 
 
+def mfma_summary(directory: str, out: str, prefix: str = "vpr::") -> None:
+    """Matrix-pipe utilisation per kernel from one PMC pass with SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE and
+    SQ_INSTS_VALU_MFMA_MOPS_BF16 (+ _F32 / SQ_INSTS_MFMA when collected):
+      mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)   (rocprofv3's MfmaUtil formula with the
+                  gfx950 facts of MI355X_MICROARCH.md: GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs)
+      mfma_flops = MOPS * 512 (rocprofv3's MfmaFlops* definition), to cross-check against the algorithmic FLOPs."""
+    names = ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU_MFMA_MOPS_F32",
+             "SQ_INSTS_MFMA", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES")
+    per = {}
+    for c in names:
+        try:
+            for k, v in collect(directory, c, prefix).items():
+                per.setdefault(k, {})[c] = sum(v) / len(v)
+                per[k]["dispatches"] = len(v)
+        except SystemExit:
+            raise
+    res = {}
+    for k, d in sorted(per.items()):
+        row = dict(d)
+        if d.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            row["mfma_util"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in d:
+            row["mfma_flops_bf16"] = d["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
+        res[k] = row
+    with open(out, "w") as f:
+        json.dump({"source_sha16": kernel_source_sha16(), "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)",
+                   "kernels": res}, f, indent=1)
+    for k, r in res.items():
+        if "mfma_util" in r:
+            print(f"{k}: MFMA util {100 * r['mfma_util']:.1f} %  ({r['dispatches']} dispatches)")
+
+
 def main():
+    if "--mfma" in sys.argv:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--mfma", required=True)
+        ap.add_argument("--out", required=True)
+        ap.add_argument("--prefix", default="vpr::")
+        a = ap.parse_args()
+        mfma_summary(a.mfma, a.out, a.prefix)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)

@@ -15,5 +15,9 @@ echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/scripts/kernel_bench.py --only knn --iters 5 > $O/${TAG}_pmc_write.log 2>&1
 echo "pmc write done"
 python3 $R/scripts/pmc_summary.py --fetch $O/${TAG}_pmc_fetch --write $O/${TAG}_pmc_write --out $O/${TAG}_knn_pmc.json
+# matrix-pipe utilisation of the MFMA kernels (SALAD GEMMs, Sinkhorn aggregation, kNN score kernel)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/${TAG}_pmc_mfma -- python3 $R/scripts/kernel_bench.py --only knn,salad --iters 5 > $O/${TAG}_pmc_mfma.log 2>&1
+echo "pmc mfma done"
+python3 $R/scripts/pmc_summary.py --mfma $O/${TAG}_pmc_mfma --out $O/${TAG}_mfma_pmc.json
 # keep the merge-back small: the per-dispatch PMC CSVs are only needed for the summary
-find $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write -name '*counter_collection.csv' -size +8M -delete || true
+find $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_mfma -name '*counter_collection.csv' -size +8M -delete || true
