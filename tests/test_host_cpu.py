@@ -110,12 +110,13 @@ def _worker(rank, world, port, N, D, B, k, ret):
     dist.destroy_process_group()
 
 
-def test_sharded_retrieval_gloo_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_retrieval_gloo_world2(world):
+    """world = 3: uneven shards (301 rows -> 100 / 100 / 101) and a gathered batch that is not a power of two."""
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), 301, 64, 3, 5, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_recall_at_k():
