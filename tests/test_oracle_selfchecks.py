@@ -1,7 +1,10 @@
 """CPU: closed-form known answers that pin the SALAD and kNN oracles (SURVEY.md §8c — both are
 'parity unpinned' by the reference, so these identities are what holds them in place)."""
 import math
+import os
 
+import numpy as np
+import pytest
 import torch
 
 from oracle import knn as oknn
@@ -107,3 +110,54 @@ def test_resize_tables_and_oracle_match_pil():
             assert np.array_equal(opre.resize_u8(img, 224, kx, xb, ky, yb), ref), (H, W, filt)
     t = opre.to_tensor_normalize(np.array([[[0, 128, 255]]], dtype=np.uint8), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
     assert t.shape == (3, 1, 1) and t[0, 0, 0] == -1.0 and t[2, 0, 0] == 1.0
+
+
+# ------------------------------------------------------------------ frozen self-oracle fixtures
+def _self_oracle():
+    import importlib.util
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_self_oracle.py")
+    spec = importlib.util.spec_from_file_location("make_self_oracle", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_oracle_reproduces_its_frozen_outputs():
+    """The oracle is the contract of the two stages the reference cannot pin; these fixtures freeze it (self-oracle,
+    not reference data): an edit that changes SALAD descriptors by > 1e-12 or any kNN index / value fails here."""
+    mso = _self_oracle()
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(G, "salad_cpu.npz"))
+    tokens, w = mso.salad_inputs(int(fx["seed"]))
+    assert float(tokens.float().sum()) == float(fx["tokens_sum"])              # same inputs regenerated
+    desc = osalad.salad_aggregate(tokens, w, dustbin=float(fx["dustbin"]), iters=3).numpy()
+    assert np.abs(desc - fx["descriptor"]).max() < 1e-12
+    fk = np.load(os.path.join(G, "knn_cpu.npz"))
+    q, gal = mso.knn_inputs(int(fk["seed"]))
+    assert float(q.sum()) == float(fk["q_sum"])
+    v, i = oknn.knn_topk(q.to(torch.bfloat16), gal.to(torch.bfloat16), 7, 11)
+    assert np.array_equal(i.numpy(), fk["idx"]) and np.array_equal(v.numpy(), fk["vals"])
+    q8, qs = oknn.quantize_fp8_rows(q)
+    g8, gs = oknn.quantize_fp8_rows(gal)
+    v8, i8 = oknn.knn_topk_fp8(q8, qs, g8, gs, 7, 11)
+    assert np.array_equal(i8.numpy(), fk["idx_fp8"]) and np.array_equal(v8.numpy(), fk["vals_fp8"])
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_frozen_self_oracle(dev):
+    from vpr_amd import ops
+    from vpr_amd.ops import SaladWeights
+    mso = _self_oracle()
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(G, "salad_cpu.npz"))
+    tokens, w = mso.salad_inputs(int(fx["seed"]))
+    out, _ = ops.salad_aggregate(tokens.to(dev), SaladWeights(**{k: v.to(dev) for k, v in w.items()}, dustbin=float(fx["dustbin"])), 3)
+    assert np.abs(out.cpu().double().numpy() - fx["descriptor"]).max() < 1e-4
+    fk = np.load(os.path.join(G, "knn_cpu.npz"))
+    q, gal = mso.knn_inputs(int(fk["seed"]))
+    v, i = ops.knn_topk(q.to(torch.bfloat16).to(dev), gal.to(torch.bfloat16).to(dev), 7, 11)
+    assert np.array_equal(i.cpu().numpy(), fk["idx"]) and np.array_equal(v.cpu().numpy(), fk["vals"])
+    q8, qs = oknn.quantize_fp8_rows(q)
+    g8, gs = oknn.quantize_fp8_rows(gal)
+    v8, i8 = ops.knn_topk_fp8(q8.to(dev), qs.to(dev), g8.to(dev), gs.to(dev), 7, 11)
+    assert np.array_equal(i8.cpu().numpy(), fk["idx_fp8"]) and np.array_equal(v8.cpu().numpy(), fk["vals_fp8"])
