@@ -19,13 +19,14 @@ def timeit(fn, n=6):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (B, N) in [(128, 50000), (192, 33333), (256, 25000), (512, 12500)]:
+for (B, N) in [(128, 50000), (192, 33333), (256, 25000), (512, 12500), (256, 250000), (512, 125000)]:
     q, gal = rows(B), rows(N)
     ws = ops.knn_workspace(B, N, D, 10, dev)
     line = f"B={B:4d} N={N:6d}:"
-    for thr, stages in ((100000, "2"), (1, "2"), (1, "3")):
+    for thr, stages, g256 in ((100000, "2", "1"), (1, "2", "0"), (1, "3", "0"), (1, "2", "1")):
         os.environ["VPR_KNN_GEMM_MIN_B"] = str(thr)
         os.environ["VPR_GEMM_NT_STAGES"] = stages
+        os.environ["VPR_KNN_FP8_GEMM256"] = g256
         t = timeit(lambda: ops.knn_scores(q, gal, ws))
-        line += f"  {'stream' if thr > 1 else 'gemm/' + stages + '-stage'} {t:7.1f} us"
+        line += f"  {'stream' if thr > 1 else ('gemm/' + stages + '-stage' if g256 == '0' else 'auto(256-tile when it fills)')} {t:7.1f} us"
     print(line, flush=True)

@@ -159,12 +159,16 @@ def test_quantize_fp8_matches_torch(dev):
     assert torch.equal(q.cpu(), q_ref)
 
 
-def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch):
-    """More than 64 queries: the block-scaled fp8 MFMA GEMM (v_mfma_scale_f32_32x32x64_f8f6f4) must produce the
-    score matrix the streaming kernel produces (same exact fp8 products, different f32 summation order)."""
+@pytest.mark.parametrize("B", [150, 256, 300, 512])
+def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch, B):
+    """More than 64 queries: the block-scaled fp8 MFMA GEMMs — the 128 x 128-tile kernel (v_mfma_scale_f32_32x32x64_f8f6f4)
+    when a 256-row query tile would be less than 3/4 full, else the 256 x 256-tile gemm256_kernel<true>
+    (v_mfma_scale_f32_16x16x128_f8f6f4, LDS-DMA in flight across barriers) — must produce the score matrix the streaming kernel produces (same exact fp8 products,
+    different f32 summation order)."""
     from vpr_amd import ops, _lib
     import ctypes
-    B, N, D, k = 200, 3001, 8448, 10
+    N, D, k = 3001, 8448, 10
+    assert _lib.lib().vpr_knn_scores_kernel_name(1, B).decode() == ("vpr::gemm256_kernel<true>" if B in (256, 512) else "vpr::gemm_nt_fp8_kernel")
     q, qs = _fp8_rows(B, D, 41)
     g, gs = _fp8_rows(N, D, 42)
     q, qs, g, gs = q.to(dev), qs.to(dev), g.to(dev), gs.to(dev)
@@ -181,7 +185,8 @@ def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch):
     assert torch.equal(i0, i1) and torch.equal(v0, v1)              # exact rescoring makes the final answer identical
 
 
-@pytest.mark.parametrize("B,N,D,k", [(64, 3000, 8448, 10), (5, 300, 128, 3), (70, 9000, 1024, 20), (300, 4000, 8448, 10)])
+@pytest.mark.parametrize("B,N,D,k", [(64, 3000, 8448, 10), (5, 300, 128, 3), (70, 9000, 1024, 20), (300, 4000, 8448, 10),
+                                     (500, 2500, 1024, 10), (384, 700, 256, 5)])      # >= 384 queries: gemm256_kernel<true>
 def test_knn_fp8_matches_oracle(dev, B, N, D, k):
     """BASELINE config 5 arithmetic (e4m3 descriptors, per-row scale) at oracle-sized N."""
     from vpr_amd import ops
@@ -295,8 +300,10 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
 @pytest.mark.parametrize("B,N,k,fp8", [
     (64, 100_000, 10, False),     # config 3 on one GPU: bf16, one 196-row tile per workgroup
     (64, 125_000, 10, True),      # config 5, one 8-way shard of the 1M gallery: multi-tile loop of knn_scores_kernel<fp8>
-    (512, 125_000, 10, True),     # config 5 on 8 GPUs: the all-gathered 512-query batch -> gemm_nt_fp8_kernel
+    (512, 125_000, 10, True),     # config 5 on 8 GPUs: the all-gathered 512-query batch -> gemm256_kernel<true>
+    (320, 60_000, 10, True),      # a 256-row tile would be 62 % full -> gemm_nt_fp8_kernel (128 x 128 tiles)
     (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard -> gemm_nt_kernel
+    (512, 125_000, 10, False),    # a 1M-row bf16 gallery on 8 GPUs: enough 256 x 256 tiles -> gemm256_kernel<false>, f32 out
     (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):

@@ -30,10 +30,40 @@ constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * TILE_ROW_BYTES;   // 64 KB per K-
 __device__ __forceinline__ int g2_a_row(int ge, bool late) { return (ge < 8 ? ge * 8 : 128 + (ge - 8) * 8) + (late ? 64 : 0); }
 __device__ __forceinline__ int g2_w_row(int ge, bool late) { return (ge >> 2) * 64 + (ge & 3) * 8 + (late ? 32 : 0); }
 
+// One operand fragment of a K-tile: the two 16-byte chunks (fch, fch + 4) of a tile row.  bf16: the operands of the two
+// 32-deep MFMAs of a 64-deep K-tile; fp8 (FP8 = true: e4m3 bytes, a 128-byte tile row = 128 K values): together the
+// 32-byte operand of ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) — same LDS image, same reads,
+// the same 256 matrix-pipe cycles per phase for twice the K: the fp8 form of this kernel runs at twice the FLOP rate
+// on the same byte stream.
+struct G2Frag { bf16x8 lo, hi; };
+__device__ __forceinline__ G2Frag g2_frag(const char* tile, int row, int fch) {
+  return G2Frag{lds_frag(tile, row, fch), lds_frag(tile, row, fch + 4)};
+}
+template <bool FP8>
+__device__ __forceinline__ f32x4 g2_mma(const G2Frag& w, const G2Frag& a, f32x4 c) {
+  if constexpr (FP8) {
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const i32x4 w0 = __builtin_bit_cast(i32x4, w.lo), w1 = __builtin_bit_cast(i32x4, w.hi);
+    const i32x4 a0 = __builtin_bit_cast(i32x4, a.lo), a1 = __builtin_bit_cast(i32x4, a.hi);
+    const i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+    const i32x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, 127, 0, 127);
+  } else {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo, a.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi, a.hi, c, 0, 0, 0);
+  }
+}
+
+// FP8: pr.A / pr.W point at e4m3 bytes (lda / ldw / K in bytes = elements), pr.a_scale / pr.w_scale are the per-row
+// f32 scales, the output is f32 = acc * a_scale[m] * w_scale[n] (no bias / relu): the kNN score tile of a 512-query
+// gathered batch against an e4m3 shard (BASELINE config 5 on 8 GPUs).
+template <bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint16_t* __restrict__ A = pr.A;
-  const uint16_t* __restrict__ W = pr.W;
+  constexpr int ES = FP8 ? 1 : 2;                       // operand element size in bytes
+  const char* __restrict__ A = reinterpret_cast<const char*>(pr.A);
+  const char* __restrict__ W = reinterpret_cast<const char*>(pr.W);
   const int M = pr.M, N = pr.N, K = pr.K;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 
   // ---- staging: this wave owns groups 2*wave, 2*wave+1 of each of the four half-tiles ----
   // index h: 0 = A-early, 1 = W-early, 2 = W-late, 3 = A-late
-  const uint16_t* src[4][2];
+  const char* src[4][2];
   int dst[4][2];
 #pragma unroll
   for (int h = 0; h < 4; ++h)
@@ -72,28 +102,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
       const bool isA = (h == 0 || h == 3), late = (h >= 2);
       const int row0 = isA ? g2_a_row(ge, late) : g2_w_row(ge, late);
       const int tr = row0 + (lane >> 3);
-      const int sw = ((lane & 7) ^ ((tr >> 1) & 7)) << 3;
+      const int sw = ((lane & 7) ^ ((tr >> 1) & 7)) << 4;      // bytes
       if (isA) {
         int r = m0 + tr;
         r = r < M ? r : M - 1;
-        const uint16_t* p = pr.a_group_rows > 0
-            ? A + (long long)(r / pr.a_group_rows) * pr.a_group_stride + (long long)(r % pr.a_group_rows) * pr.lda
-            : A + (long long)r * pr.lda;
+        const char* p = pr.a_group_rows > 0
+            ? A + ((long long)(r / pr.a_group_rows) * pr.a_group_stride + (long long)(r % pr.a_group_rows) * pr.lda) * ES
+            : A + (long long)r * pr.lda * ES;
         src[h][j] = p + sw;
         dst[h][j] = row0 * TILE_ROW_BYTES;
       } else {
         int r = n0 + tr;
         r = r < N ? r : N - 1;
-        src[h][j] = W + (long long)r * pr.ldw + sw;
+        src[h][j] = W + (long long)r * pr.ldw * ES + sw;
         dst[h][j] = G2_BM * TILE_ROW_BYTES + row0 * TILE_ROW_BYTES;
       }
     }
-  const int nk = K >> 6;
+  const int nk = (K * ES) >> 7;                          // 128 bytes of every row per K-tile
   auto issue = [&](int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1 (kt clamped: dummy tail)
     const int kc = kt < nk ? kt : nk - 1;
     char* base = smem + (kc & 1) * G2_BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(src[h][j] + kc * 64, base + dst[h][j]);
+    for (int j = 0; j < 2; ++j) glds16(src[h][j] + kc * 128, base + dst[h][j]);
   };
 
   f32x4 acc[2][2][4][2];   // [qi][qj][rb][cb]: rows n = wc*64 + qj*32 + cb*16 + 4g+e, cols m = wr*128 + qi*64 + rb*16 + lane&15
@@ -125,17 +155,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   for (int kt = 0; kt < nk; ++kt) {
     const char* ta = smem + (kt & 1) * G2_BUF_BYTES;
     const char* tw = ta + G2_BM * TILE_ROW_BYTES;
-    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    G2Frag a[4], b0[2], b1[2];
 
     // ---- phase 1: A rows of quadrant-row 0, W rows of quadrant-col 0 ----
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 2; ++cb) b0[cb] = g2_frag(tw, wc * 64 + cb * 16 + frow, fch);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) b0[cb][s] = lds_frag(tw, wc * 64 + cb * 16 + frow, fch + 4 * s);
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) a[rb][s] = lds_frag(ta, wr * 128 + rb * 16 + frow, fch + 4 * s);
+    for (int rb = 0; rb < 4; ++rb) a[rb] = g2_frag(ta, wr * 128 + rb * 16 + frow, fch);
     issue(3, kt + 1);
     asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires W-late(kt) for phase 2
     __builtin_amdgcn_s_barrier();
@@ -143,18 +169,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          acc[0][0][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[cb][s], a[rb][s], acc[0][0][rb][cb], 0, 0, 0);
+      for (int cb = 0; cb < 2; ++cb) acc[0][0][rb][cb] = g2_mma<FP8>(b0[cb], a[rb], acc[0][0][rb][cb]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
 
     // ---- phase 2: W rows of quadrant-col 1 ----
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) b1[cb][s] = lds_frag(tw, wc * 64 + 32 + cb * 16 + frow, fch + 4 * s);
+    for (int cb = 0; cb < 2; ++cb) b1[cb] = g2_frag(tw, wc * 64 + 32 + cb * 16 + frow, fch);
     issue(0, kt + 2);          // A-early slot: both groups' phase-1 reads completed two barriers ago
     asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires A-late(kt) for phase 3
     __builtin_amdgcn_s_barrier();
@@ -162,18 +183,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          acc[0][1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[cb][s], a[rb][s], acc[0][1][rb][cb], 0, 0, 0);
+      for (int cb = 0; cb < 2; ++cb) acc[0][1][rb][cb] = g2_mma<FP8>(b1[cb], a[rb], acc[0][1][rb][cb]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
 
     // ---- phase 3: A rows of quadrant-row 1 ----
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) a[rb][s] = lds_frag(ta, wr * 128 + 64 + rb * 16 + frow, fch + 4 * s);
+    for (int rb = 0; rb < 4; ++rb) a[rb] = g2_frag(ta, wr * 128 + 64 + rb * 16 + frow, fch);
     issue(1, kt + 2);          // W-early slot (read in phase 1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -181,10 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          acc[1][1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[cb][s], a[rb][s], acc[1][1][rb][cb], 0, 0, 0);
+      for (int cb = 0; cb < 2; ++cb) acc[1][1][rb][cb] = g2_mma<FP8>(b1[cb], a[rb], acc[1][1][rb][cb]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
 
@@ -196,10 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          acc[1][0][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[cb][s], a[rb][s], acc[1][0][rb][cb], 0, 0, 0);
+      for (int cb = 0; cb < 2; ++cb) acc[1][0][rb][cb] = g2_mma<FP8>(b0[cb], a[rb], acc[1][0][rb][cb]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   }
@@ -216,12 +226,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
     for (int cb = 0; cb < 2; ++cb) {
       const int n = n0 + wc * 64 + qj * 32 + cb * 16 + 4 * g;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pr.bias != nullptr) {
-        if (n + 3 < N) b = *reinterpret_cast<const float4*>(pr.bias + n);
+      const float* colv = FP8 ? pr.w_scale : pr.bias;        // bf16: additive bias; fp8: the W rows' scales (multiplicative)
+      if (colv != nullptr) {
+        if (n + 3 < N) b = *reinterpret_cast<const float4*>(colv + n);
         else {
-          if (n < N) b.x = pr.bias[n];
-          if (n + 1 < N) b.y = pr.bias[n + 1];
-          if (n + 2 < N) b.z = pr.bias[n + 2];
+          if (n < N) b.x = colv[n];
+          if (n + 1 < N) b.y = colv[n + 1];
+          if (n + 2 < N) b.z = colv[n + 2];
         }
       }
       bias4[qj][cb] = b;
@@ -235,14 +246,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       char* rowp = smem + (wr * 64 + rb * 16 + (lane & 15)) * pitch;
+      float as = 1.f;
+      if constexpr (FP8) as = pr.a_scale[min(m0 + wr * 128 + qi * 64 + rb * 16 + (lane & 15), M - 1)];
 #pragma unroll
       for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           const int nl = wc * 64 + qj * 32 + cb * 16 + 4 * g;
           const float4 b = bias4[qj][cb];
-          float v0 = acc[qi][qj][rb][cb][0] + b.x, v1 = acc[qi][qj][rb][cb][1] + b.y;
-          float v2 = acc[qi][qj][rb][cb][2] + b.z, v3 = acc[qi][qj][rb][cb][3] + b.w;
+          float v0, v1, v2, v3;
+          if constexpr (FP8) {                                 // (acc * a_scale) * w_scale: the order of the other fp8 score paths
+            v0 = acc[qi][qj][rb][cb][0] * as * b.x; v1 = acc[qi][qj][rb][cb][1] * as * b.y;
+            v2 = acc[qi][qj][rb][cb][2] * as * b.z; v3 = acc[qi][qj][rb][cb][3] * as * b.w;
+          } else {
+            v0 = acc[qi][qj][rb][cb][0] + b.x; v1 = acc[qi][qj][rb][cb][1] + b.y;
+            v2 = acc[qi][qj][rb][cb][2] + b.z; v3 = acc[qi][qj][rb][cb][3] + b.w;
+          }
           if (pr.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
           if (pr.out_is_bf16) {
             uint2 o;
@@ -282,6 +301,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   }
 }
 
+constexpr size_t G2_LDS = 128 * (G2_BN * 4 + 16);   // >= the two K-tile buffers (128 KB); sized by the f32 epilogue staging
+
 int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   GemmProblem g = in;
   if (!g.A || !g.W || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return VPR_ERR_INVALID_ARG;
@@ -291,15 +312,35 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
     return VPR_ERR_UNSUPPORTED;
   g.tiles_m = (g.M + G2_BM - 1) / G2_BM;
   g.tiles_n = (g.N + G2_BN - 1) / G2_BN;
-  constexpr size_t lds = 128 * (G2_BN * 4 + 16);   // >= the two K-tile buffers (128 KB); sized by the f32 epilogue staging
+  g.a_scale = g.w_scale = nullptr;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G2_LDS) != hipSuccess)
       return VPR_ERR_LAUNCH;
     attr = true;
   }
-  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), lds, stream, g));
+  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g));
+  return VPR_OK;
+}
+
+// e4m3 operands with per-row scales, f32 out: C[m][n] = a_scale[m] * w_scale[n] * sum_k A[m][k] W[n][k]; K % 128 == 0, K >= 256.
+int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
+                       float* C, int ldc, int M, int N, int K, hipStream_t stream) {
+  if (!A || !W || !C || !a_scale || !w_scale || M <= 0 || N <= 0 || K <= 0) return VPR_ERR_INVALID_ARG;
+  if ((K % 128) || K < 256 || lda < K || ldw < K || ldc < N || (lda % 16) || (ldw % 16) || (ldc % 4)) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C)) & 15)
+    return VPR_ERR_UNSUPPORTED;
+  GemmProblem g{reinterpret_cast<const uint16_t*>(A), lda, 0, 0, reinterpret_cast<const uint16_t*>(W), ldw, nullptr, 0,
+                C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale};
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)G2_LDS) != hipSuccess)
+      return VPR_ERR_LAUNCH;
+    attr = true;
+  }
+  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<true>, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g));
   return VPR_OK;
 }
 

@@ -912,6 +912,15 @@ static int knn_check(const KnnOperands& o, int D) {
   return VPR_OK;
 }
 
+// 256-row query tiles pay when at least 3/4 of their rows are real queries (256 gathered queries = 4 GPUs, 512 = 8 GPUs);
+// VPR_KNN_FP8_GEMM256=0 forces the 128 x 128 kernel (A/B).
+static bool knn_fp8_use_gemm256(int B) {
+  const char* e = getenv("VPR_KNN_FP8_GEMM256");
+  if (e && !atoi(e)) return false;
+  const int tiles = (B + 255) / 256;
+  return 4 * B >= 3 * tiles * 256;
+}
+
 int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_bytes, int k_for_plan,
                hipStream_t stream) {
   KnnPlan p;
@@ -927,9 +936,21 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // 192 x 33k 406 / 300, 256 x 25k 477 / 185, 512 x 12.5k 702 / 151 (scripts/knn_b_sweep.py).
   const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the crossover
   const int gemm_min_b = genv ? atoi(genv) : 65;
+  // e4m3, >= 384 gathered queries (512 at 8 GPUs): the 256 x 256-tile kernel with its LDS-DMA stream kept in flight across
+  // barriers (gemm256.hip, fp8 form); a 128-256-query batch would leave half of such a tile row empty.
+  if (o.fp8 && B >= gemm_min_b && D >= 256 && knn_fp8_use_gemm256(B))
+    return launch_gemm256_fp8(static_cast<const uint8_t*>(o.q), D, o.q_scale, static_cast<const uint8_t*>(o.g), D,
+                              o.g_scale, S, p.ldS, B, N, D, stream);
   if (o.fp8 && B >= gemm_min_b)      // block-scaled fp8 MFMA GEMM (twice the bf16 rate), scales in its epilogue
     return launch_gemm_nt_fp8(static_cast<const uint8_t*>(o.q), D, o.q_scale, static_cast<const uint8_t*>(o.g), D,
                               o.g_scale, S, p.ldS, B, N, D, stream);
+  // bf16, same rule plus enough 256 x 256 tiles to fill the chip (a 12.5k-row shard gives 98: the 128 x 128 kernel's 392
+  // workgroups win there; a 125k-row shard gives 978)
+  if (!o.fp8 && B >= gemm_min_b && knn_fp8_use_gemm256(B) && (long long)((B + 255) / 256) * ((N + 255) / 256) >= 256) {
+    const GemmProblem g{static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr, 0,
+                        S, p.ldS, 0, B, N, D, 0, 0};
+    return launch_gemm256(g, stream);
+  }
   if (!o.fp8 && B >= gemm_min_b)
     return launch_gemm_nt(static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr,
                           0, S, p.ldS, 0, B, N, D, stream);
@@ -1093,10 +1114,13 @@ extern "C" size_t vpr_knn_workspace_bytes(int B, int N, int D, int k) {
 }
 
 extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B) {
+  // (bf16 batches of >= 192 queries against shards of >= 65k rows run vpr::gemm256_kernel<false>; this query has no N
+  // and names the small-shard kernel, which is what bench.py's 100k / 8 shards launch)
   // mirrors the dispatch of knn_scores(): what a kernel trace (rocprofv3) will show for this call
   const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
   const int gemm_min_b = genv ? atoi(genv) : 65;
-  if (B >= gemm_min_b) return is_fp8 ? "vpr::gemm_nt_fp8_kernel" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
+  const bool g2 = knn_fp8_use_gemm256(B);
+  if (B >= gemm_min_b) return is_fp8 ? (g2 ? "vpr::gemm256_kernel<true>" : "vpr::gemm_nt_fp8_kernel") : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
   const char* venv = getenv("VPR_KNN_VARIANT");
   const int variant = venv ? atoi(venv) : 0;
   if (is_fp8) {
