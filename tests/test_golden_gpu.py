@@ -265,3 +265,53 @@ def test_validate_and_test_swin_entry_point(dev, tmp_path, capsys):
     assert tcsv["filename"].tolist() == sorted(res["test_filenames"])
     with open(sdir / "test_predictions_sorted.csv") as f:
         assert all(len(x.split(".")[-1].strip()) == 6 for x in f.read().splitlines()[1].split(",")[1:])      # '%.6f'
+
+
+def test_angle_validation_entry_point(dev, tmp_path, capsys):
+    """Angle validation loop of the reference (angle_prediction/efficient_net/validation_script.py:162-221; the
+    backbone there is out of scope, the loop / metric / prints / CSV are not) driving a Swin sin/cos model on the HIP
+    path: unit (sin, cos) -> atan2 -> [0, 360) degrees, MAAE, validation_predictions.csv, sorted test CSV; against the
+    same arithmetic in f32 torch (HF pooler -> Linear -> F.normalize)."""
+    import pandas as pd
+    from PIL import Image
+    from transformers import SwinConfig, SwinModel
+    from vpr_amd import evaluate, modules
+    from vpr_amd.preprocess import IMAGENET_MEAN, IMAGENET_STD, ResizeNormalize
+    rng = np.random.default_rng(8)
+    vdir, tdir = tmp_path / "val", tmp_path / "test"
+    vdir.mkdir(), tdir.mkdir()
+    names = [f"img_{i:04d}.jpg" for i in range(6)]
+    for n in names:
+        Image.fromarray(rng.integers(0, 256, (240, 320, 3), dtype=np.uint8)).save(vdir / n, quality=95)
+    for n in ("img_0011.png", "img_0010.png"):
+        Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(tdir / n)
+    angles = rng.integers(0, 360, 6)
+    pd.DataFrame({"filename": names, "timestamp": "12:00", "latitude": 0, "longitude": 0, "angle": angles,
+                  "Region_ID": 1}).to_csv(tmp_path / "labels_val.csv", index=False)
+    torch.manual_seed(6)
+    model = modules.SwinSinCosRegressionModel(SwinModel(SwinConfig()).eval())
+    with torch.no_grad():
+        model.regressor.weight.mul_(30.0)                         # spread the predictions over the circle
+    res = evaluate.calculate_angle_validation_scores(model, str(tmp_path / "labels_val.csv"), str(vdir),
+                                                     str(tmp_path / "validation_predictions.csv"), test_image_dir=str(tdir),
+                                                     test_csv=str(tmp_path / "test_pred.csv"), batch_size=4)
+    printed = capsys.readouterr().out
+    assert "Total validation samples processed: 6" in printed and "Mean Absolute Angular Error (MAAE):" in printed
+    prep = ResizeNormalize(224, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
+    want = []
+    with torch.no_grad():
+        for n in names:
+            u8 = torch.from_numpy(np.array(Image.open(vdir / n).convert("RGB"))[None]).to(dev)
+            out = torch.nn.functional.normalize(model.regressor(model.backbone(pixel_values=prep(u8)).pooler_output), dim=1, p=2, eps=1e-6)
+            want.append(float((torch.rad2deg(torch.atan2(out[0, 0], out[0, 1])) + 360.0) % 360.0))
+    want = np.array(want)
+    d = np.abs(res["pred_deg"] - want)
+    assert np.minimum(d, 360 - d).max() < 0.05                    # degrees
+    e = np.abs(want - angles)
+    assert res["maae"] == pytest.approx(np.minimum(e, 360 - e).mean(), abs=0.05)
+    csv = pd.read_csv(tmp_path / "validation_predictions.csv")
+    assert list(csv.columns) == ["filename", "true_angle", "predicted_angle", "angular_error"] and csv["filename"].tolist() == names
+    assert np.allclose(csv["angular_error"], np.minimum(np.abs(csv["predicted_angle"] - csv["true_angle"]),
+                                                        360 - np.abs(csv["predicted_angle"] - csv["true_angle"])))
+    t = pd.read_csv(tmp_path / "test_pred.csv")
+    assert list(t.columns) == ["filename", "predicted_angle_degrees"] and t["filename"].tolist() == ["img_0010.png", "img_0011.png"]

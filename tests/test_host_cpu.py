@@ -203,6 +203,19 @@ def test_csv_writers_reproduce_reference_files(tmp_path):
     out = tmp_path / "preds.csv"
     reports.write_id_sorted_preds(str(out), names, df[["latitude", "longitude"]].values)
     assert out.read_text() == ref
+    # angle CSVs (angle_prediction/efficient_net/validation_script.py:213-220, test_script.py:269-276): rows of the
+    # reference's committed final_csvs/validation_predictions.csv and test_pred.csv
+    ref = open(os.path.join(here, "ref_angle_validation_head.csv")).read()
+    df = pd.read_csv(os.path.join(here, "ref_angle_validation_head.csv"))
+    out = tmp_path / "angle_val.csv"
+    reports.write_angle_validation_csv(str(out), df["filename"], df["true_angle"].to_numpy(),
+                                       df["predicted_angle"].to_numpy().astype(np.float32))
+    assert out.read_text() == ref                                # incl. the recomputed angular_error column
+    ref = open(os.path.join(here, "ref_angle_test_pred_head.csv")).read()
+    df = pd.read_csv(os.path.join(here, "ref_angle_test_pred_head.csv")).sample(frac=1.0, random_state=2)
+    out = tmp_path / "angle_test.csv"
+    reports.write_angle_test_csv(str(out), df["filename"], df["predicted_angle_degrees"].to_numpy().astype(np.float32))
+    assert out.read_text() == ref
     assert reports.extract_id("images_val/img_0042.jpg") == 42
     txt = reports.format_metrics(np.array([[1.0, 2.0], [3.0, 5.0]]), np.array([[1.5, 2.0], [2.0, 3.0]]))
     assert "MAE Latitude: 0.750000" in txt and "MAE Longitude: 1.000000" in txt

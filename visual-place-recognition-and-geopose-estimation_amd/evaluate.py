@@ -219,3 +219,64 @@ def validate_and_test_swin(model, val_csv_path: str, val_image_dir: str, test_im
         if verbose:
             print(f"Successfully saved sorted test prediction results to: {path}")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Angle (sin/cos head) validation: loop, metric, prints and CSV layout of angle_prediction/efficient_net/
+# validation_script.py:162-221 / test_script.py:255-276 — the reference's only angle-validation callers.  Their
+# backbone (EfficientNet-B0) is out of scope; the loop is backbone-agnostic and here serves the Swin / DINOv2 sin/cos
+# models of vpr_amd.modules (output order [sin, cos]; order="cossin" decodes the EfficientNet convention).
+@torch.no_grad()
+def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, results_csv: Optional[str] = None, *,
+                                      test_image_dir: Optional[str] = None, test_csv: Optional[str] = None,
+                                      checkpoint_path: Optional[str] = None, order: str = "sincos", image_size: int = 224,
+                                      batch_size: int = 32, device: str = "cuda", verbose: bool = True, prep=None) -> dict:
+    """`model`: pixel_values -> [B, 2] (SwinSinCosRegressionModel, SwinAngleRegressorSinCos, DinoV2AngleRegressorSinCos).
+    Decoding as validation_script.py:179-182: atan2 -> degrees -> (+360) % 360; error min(d, 360 - d) (:188-189); MAAE =
+    mean over the processed samples (:200-206).  Preprocessing default = the HF Swin processor (bicubic resize to
+    `image_size`, /255, ImageNet statistics) on the GPU; pass `prep` for another one (dtype must suit the model)."""
+    import glob
+    if order not in ("sincos", "cossin"):
+        raise ValueError("order must be 'sincos' or 'cossin'")
+    dev = torch.device(device)
+    model = model.to(dev).eval()
+    if checkpoint_path:
+        load_reference_checkpoint(model, checkpoint_path)
+    prep = prep or ResizeNormalize(image_size, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
+
+    def predict_deg(directory, names):
+        out = torch.empty((len(names), 2), dtype=torch.float32, device=dev)
+        for idxs, part in _batches_by_size(directory, names, batch_size):
+            out[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(directory, part, dev))).float()
+        s, c = (out[:, 0], out[:, 1]) if order == "sincos" else (out[:, 1], out[:, 0])
+        return ((torch.rad2deg(torch.atan2(s, c)) + 360.0) % 360.0).cpu().numpy()            # f32, as the script's tensors
+
+    df = _existing_rows(val_csv_path, image_dir)
+    names = df["filename"].tolist()
+    pred = predict_deg(image_dir, names)
+    true = df["angle"].to_numpy()
+    diff = np.abs(pred - true.astype(np.float32))
+    err = np.minimum(diff, np.float32(360.0) - diff)
+    maae = float(err.astype(np.float64).sum() / max(len(names), 1))
+    if verbose:
+        print("\n===================================")
+        print("Prediction complete.")
+        print(f"Total validation samples processed: {len(names)}")
+        print(f"Mean Absolute Angular Error (MAAE): {maae:.4f} degrees")
+        print("===================================")
+    res = {"filenames": names, "pred_deg": pred, "true_deg": true, "angular_error": err, "maae": maae}
+    if results_csv:
+        reports.write_angle_validation_csv(results_csv, names, true, pred)
+        if verbose:
+            print(f"Prediction results saved to: {results_csv}")
+    if test_image_dir and os.path.isdir(test_image_dir):
+        paths = []
+        for ext in IMAGE_EXTENSIONS:
+            paths.extend(glob.glob(os.path.join(test_image_dir, ext)))
+        tnames = sorted(os.path.basename(p) for p in paths if _loadable(p))
+        if tnames:
+            tpred = predict_deg(test_image_dir, tnames)
+            res.update(test_filenames=tnames, test_pred_deg=tpred)
+            if test_csv:
+                reports.write_angle_test_csv(test_csv, tnames, tpred)
+    return res

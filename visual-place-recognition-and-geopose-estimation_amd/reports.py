@@ -56,3 +56,26 @@ def format_metrics(preds: np.ndarray, targets: np.ndarray) -> str:
             f"  Mean Absolute Error (MAE): {m['mae']:.6f}\n"
             f"  MAE Latitude: {m['mae_lat']:.6f}\n"
             f"  MAE Longitude: {m['mae_lon']:.6f}")
+
+
+def write_angle_validation_csv(path: str, filenames: Sequence[str], true_deg, pred_deg) -> pd.DataFrame:
+    """filename,true_angle,predicted_angle,angular_error — angle_prediction/efficient_net/validation_script.py:213-220
+    (the only angle-validation CSV layout in the reference; committed example:
+    angle_prediction/efficient_net/final_csvs/validation_predictions.csv).  Predictions are f32 values widened to
+    Python floats (the script's `.cpu().tolist()`), the error column is recomputed from the two columns in f64."""
+    pred = [float(np.float32(p)) for p in np.asarray(pred_deg).ravel()]
+    true = np.asarray(true_deg).ravel().tolist()
+    df = pd.DataFrame({"filename": list(filenames), "true_angle": true, "predicted_angle": pred})
+    df["angular_error"] = df.apply(lambda row: min(abs(row["predicted_angle"] - row["true_angle"]),
+                                                   360 - abs(row["predicted_angle"] - row["true_angle"])), axis=1)
+    df.to_csv(path, index=False)
+    return df
+
+
+def write_angle_test_csv(path: str, filenames: Sequence[str], pred_deg) -> pd.DataFrame:
+    """filename,predicted_angle_degrees sorted by filename — angle_prediction/efficient_net/test_script.py:269-276."""
+    df = pd.DataFrame({"filename": list(filenames),
+                       "predicted_angle_degrees": [float(np.float32(p)) for p in np.asarray(pred_deg).ravel()]})
+    df = df.sort_values(by="filename")
+    df.to_csv(path, index=False)
+    return df
