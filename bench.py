@@ -357,7 +357,7 @@ def main():
     # HBM traffic of the score kernel from the PMC counters (profiles/, collected as MI355X_MICROARCH.md §HBM prescribes):
     # quoted only if the summary was measured on THIS kernel source and names the kernel this run launched.
     traffic, traffic_source = None, None
-    score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq).decode()
+    score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq, n_shard).decode()
     pmc = os.path.join(ROOT, "profiles", "r02_knn_pmc.json")
     if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64 and a.knn_dtype == "bf16":
         try:

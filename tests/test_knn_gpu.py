@@ -168,7 +168,7 @@ def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch, B):
     from vpr_amd import ops, _lib
     import ctypes
     N, D, k = 3001, 8448, 10
-    assert _lib.lib().vpr_knn_scores_kernel_name(1, B).decode() == ("vpr::gemm256_kernel<true>" if B in (256, 512) else "vpr::gemm_nt_fp8_kernel")
+    assert _lib.lib().vpr_knn_scores_kernel_name(1, B, N).decode() == ("vpr::gemm256_kernel<true>" if B in (256, 512) else "vpr::gemm_nt_fp8_kernel")
     q, qs = _fp8_rows(B, D, 41)
     g, gs = _fp8_rows(N, D, 42)
     q, qs, g, gs = q.to(dev), qs.to(dev), g.to(dev), gs.to(dev)
@@ -299,12 +299,13 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
 
 @pytest.mark.parametrize("B,N,k,fp8", [
     (64, 100_000, 10, False),     # config 3 on one GPU: bf16, one 196-row tile per workgroup
-    (64, 125_000, 10, True),      # config 5, one 8-way shard of the 1M gallery: multi-tile loop of knn_scores_kernel<fp8>
+    (64, 150_000, 10, False),     # bf16 shard above 106k rows: the 256-row tile form, knn_scores_kernel<false, 256, 2, 4>
+    (64, 125_000, 10, True),      # config 5, one 8-way shard of the 1M gallery: one 244-row tile per workgroup (256-row form)
     (512, 125_000, 10, True),     # config 5 on 8 GPUs: the all-gathered 512-query batch -> gemm256_kernel<true>
     (320, 60_000, 10, True),      # a 256-row tile would be 62 % full -> gemm_nt_fp8_kernel (128 x 128 tiles)
     (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard -> gemm_nt_kernel
     (512, 125_000, 10, False),    # a 1M-row bf16 gallery on 8 GPUs: enough 256 x 256 tiles -> gemm256_kernel<false>, f32 out
-    (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU
+    (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU: 8 tiles of 245 rows per workgroup
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):
     _full_size_check(dev, B, N, k, fp8, seed=B + N)

@@ -912,6 +912,12 @@ static int knn_check(const KnnOperands& o, int D) {
   return VPR_OK;
 }
 
+// rows per workgroup of the fully resident grid (2 per CU) above one 208-row tile
+static bool knn_tall_tiles(int N) {
+  const int slots = num_cus() * 2;
+  return (N + slots - 1) / slots > 208;
+}
+
 // 256-row query tiles pay when at least 3/4 of their rows are real queries (256 gathered queries = 4 GPUs, 512 = 8 GPUs);
 // VPR_KNN_FP8_GEMM256=0 forces the 128 x 128 kernel (A/B).
 static bool knn_fp8_use_gemm256(int B) {
@@ -961,6 +967,10 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   const int variant = venv ? atoi(venv) : 0;
   int tr = 208, wgpc = 2;                         // default: 13 row blocks, 2 workgroups per CU
   if (variant == 2) { tr = 144; wgpc = 3; }
+  // Shards whose workgroups own more than one 208-row tile (N > 106k) take 256-row tiles: 16 row blocks, 2 x 80 KB = the
+  // whole 160 KB of LDS, fewer tiles and 20 % less query re-staging: +2.3 % at 500k bf16 rows, +1.4 % on the 1M-row e4m3
+  // call; a 125k-row shard becomes one 244-row tile per workgroup instead of two of 122 (scripts/knn_ab.py, knn_ab_fp8.py).
+  if (variant == 3 || (variant == 0 && knn_tall_tiles(N))) { tr = 256; wgpc = 2; }
   const int slots = num_cus() * wgpc;
   // Fully resident, balanced grid; never more workgroups than 16-row blocks of gallery.
   int nwg = slots;
@@ -985,18 +995,23 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // matrix in L2 / Infinity Cache): +4.6 % on the bare stream, +5.2 % on this kernel at 100k rows.
   if (o.fp8) {
     if (variant == 2) VPR_KNN_LAUNCH(true, 144, 3, 4);
+    else if (tr == 256) VPR_KNN_LAUNCH(true, 256, 2, 4);
     else if (variant == 1) VPR_KNN_LAUNCH(true, 208, 2, 0);
     else VPR_KNN_LAUNCH(true, 208, 2, 4);
   } else {
     switch (variant) {
       case 1: VPR_KNN_LAUNCH(false, 208, 2, 0); break;    // default cache policy (round 1's kernel)
       case 2: VPR_KNN_LAUNCH(false, 144, 3, 4); break;    // the round-1 first cut: 9 blocks, 3 per CU
+      case 3: VPR_KNN_LAUNCH(false, 256, 2, 4); break;    // 16 blocks, all of the LDS
+      case 4: VPR_KNN_LAUNCH(false, 208, 2, 4); break;    // 13 blocks whatever the shard size (A/B against the tall tiles)
 #ifdef VPR_ABLATION     // timing-only builds (WRONG scores): never in the shipped library
       case 11: VPR_KNN_LAUNCH(false, 208, 2, 5); break;   // ablation: no MFMA after the first K-step
       case 12: VPR_KNN_LAUNCH(false, 208, 2, 6); break;   // ablation: no query staging after the first K-step
       case 13: VPR_KNN_LAUNCH(false, 208, 2, 7); break;   // ablation: both (pure gallery stream + barriers)
 #endif
-      default: VPR_KNN_LAUNCH(false, 208, 2, 4); break;
+      default:
+        if (tr == 256) VPR_KNN_LAUNCH(false, 256, 2, 4); else VPR_KNN_LAUNCH(false, 208, 2, 4);
+        break;
     }
   }
 #undef VPR_KNN_LAUNCH
@@ -1113,21 +1128,23 @@ extern "C" size_t vpr_knn_workspace_bytes(int B, int N, int D, int k) {
   return knn_plan(B, N, D, k, &p) ? p.total : 0;
 }
 
-extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B) {
-  // (bf16 batches of >= 192 queries against shards of >= 65k rows run vpr::gemm256_kernel<false>; this query has no N
-  // and names the small-shard kernel, which is what bench.py's 100k / 8 shards launch)
+extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N) {
   // mirrors the dispatch of knn_scores(): what a kernel trace (rocprofv3) will show for this call
   const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
   const int gemm_min_b = genv ? atoi(genv) : 65;
   const bool g2 = knn_fp8_use_gemm256(B);
-  if (B >= gemm_min_b) return is_fp8 ? (g2 ? "vpr::gemm256_kernel<true>" : "vpr::gemm_nt_fp8_kernel") : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
+  if (B >= gemm_min_b) {
+    if (is_fp8) return g2 ? "vpr::gemm256_kernel<true>" : "vpr::gemm_nt_fp8_kernel";
+    return g2 && (long long)((B + 255) / 256) * ((N + 255) / 256) >= 256 ? "vpr::gemm256_kernel<false>" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
+  }
   const char* venv = getenv("VPR_KNN_VARIANT");
   const int variant = venv ? atoi(venv) : 0;
+  const bool tall = variant == 3 || (variant == 0 && knn_tall_tiles(N));
   if (is_fp8) {
-    return variant == 2 ? "vpr::knn_scores_kernel<true, 144, 3, 4>"
+    return variant == 2 ? "vpr::knn_scores_kernel<true, 144, 3, 4>" : tall ? "vpr::knn_scores_kernel<true, 256, 2, 4>"
          : variant == 1 ? "vpr::knn_scores_kernel<true, 208, 2, 0>" : "vpr::knn_scores_kernel<true, 208, 2, 4>";
   }
-  return variant == 2 ? "vpr::knn_scores_kernel<false, 144, 3, 4>"
+  return variant == 2 ? "vpr::knn_scores_kernel<false, 144, 3, 4>" : tall ? "vpr::knn_scores_kernel<false, 256, 2, 4>"
        : variant == 1 ? "vpr::knn_scores_kernel<false, 208, 2, 0>" : "vpr::knn_scores_kernel<false, 208, 2, 4>";
 }
 
