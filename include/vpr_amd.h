@@ -129,7 +129,10 @@ int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D
 /* Stage entry points of vpr_knn_topk (same workspace layout), so the dominant kernel can be
  * timed by itself (bench.py roofline) and tested by itself.
  *   scores:  S[b, n] = <q_b, g_n>  (bf16 MFMA, f32 accumulate)  -> workspace
- *   select:  per-query candidate selection + exact rescoring + final ordering           */
+ *            B <= 64: the HBM-streaming kernel (one gallery pass, 208- or 256-row tiles by shard size); B > 64 (the
+ *            all-gathered batch of a multi-GPU job): an MFMA GEMM, 128 x 128 tiles or — 256-row query tiles at least 3/4
+ *            full and >= 256 tiles — the 256 x 256-tile kernel.  vpr_knn_scores_kernel_name() tells which.
+ *   select:  per-query candidate selection + exact rescoring + final ordering + certificate (see "Checked forms") */
 int vpr_knn_scores(const uint16_t* q, const uint16_t* gallery, int B, int N, int D,
                    void* workspace, size_t workspace_bytes, void* stream);
 int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
