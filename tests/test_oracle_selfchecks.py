@@ -161,3 +161,29 @@ def test_hip_path_matches_the_frozen_self_oracle(dev):
     g8, gs = oknn.quantize_fp8_rows(gal)
     v8, i8 = ops.knn_topk_fp8(q8.to(dev), qs.to(dev), g8.to(dev), gs.to(dev), 7, 11)
     assert np.array_equal(i8.cpu().numpy(), fk["idx_fp8"]) and np.array_equal(v8.cpu().numpy(), fk["vals_fp8"])
+
+
+def test_sinkhorn_solver_equals_hf_superglue_log_sinkhorn():
+    """An INDEPENDENT implementation of the log-domain Sinkhorn iteration is importable: Hugging Face's SuperGlue port
+    (transformers.models.superglue.modeling_superglue.log_sinkhorn_iterations) — the routine SALAD's solver descends
+    from (SuperGlue's log_optimal_transport, arXiv:1911.11763 §3.3; SALAD arXiv:2311.15937 §3.2 reuses it with a
+    dustbin ROW only).  With SALAD's marginals it must give the oracle's log-assignment: this pins the solver half of
+    oracle/salad.py against a third party; the SALAD-specific wiring around it (marginals, dustbin row, normalisation
+    order, MLP layout) stays pinned by the closed-form identities above only."""
+    sg = pytest.importorskip("transformers.models.superglue.modeling_superglue")
+    g = torch.Generator().manual_seed(12)
+    B, m, n = 3, 64, 256
+    S = torch.randn(B, m + 1, n, generator=g, dtype=torch.float64) * 2.5
+    norm = -math.log(n + m)
+    log_a = torch.full((B, m + 1), norm, dtype=torch.float64)
+    log_a[:, -1] += math.log(n - m)
+    log_b = torch.full((B, n), norm, dtype=torch.float64)
+    for iters in (1, 3, 10):
+        ours = osalad.log_otp_solver(log_a, log_b, S, iters)
+        theirs = sg.log_sinkhorn_iterations(S, log_a, log_b, iters)
+        assert (ours - theirs).abs().max().item() < 1e-12
+    # and through the oracle's public entry (dustbin row appended, exp, dustbin dropped later)
+    P = osalad.matching_probs(S[:, :m], dustbin=0.3, num_iters=3)
+    S_aug = torch.cat([S[:, :m], torch.full((B, 1, n), 0.3, dtype=torch.float64)], 1)
+    P_hf = torch.exp(sg.log_sinkhorn_iterations(S_aug, log_a, log_b, 3) - norm)
+    assert (P - P_hf).abs().max().item() < 1e-12
