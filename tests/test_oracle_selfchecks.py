@@ -187,3 +187,19 @@ def test_sinkhorn_solver_equals_hf_superglue_log_sinkhorn():
     S_aug = torch.cat([S[:, :m], torch.full((B, 1, n), 0.3, dtype=torch.float64)], 1)
     P_hf = torch.exp(sg.log_sinkhorn_iterations(S_aug, log_a, log_b, 3) - norm)
     assert (P - P_hf).abs().max().item() < 1e-12
+
+
+def test_knn_oracle_agrees_with_numpy_brute_force():
+    """The kNN contract written a second time with numpy only (f64 products of the bf16 values, f32 rounding, stable
+    argsort = value desc / index asc) — guards the torch-based oracle against a sort / gather mistake; includes ties."""
+    g = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.randn(6, 96, generator=g), dim=1).to(torch.bfloat16)
+    gal = torch.nn.functional.normalize(torch.randn(500, 96, generator=g), dim=1).to(torch.bfloat16)
+    gal[40] = gal[7]; gal[300] = gal[7]
+    q[0] = gal[7]
+    v, i = oknn.knn_topk(q, gal, 9, index_base=100)
+    s = (q.double().numpy() @ gal.double().numpy().T).astype(np.float32)
+    order = np.argsort(-s, axis=1, kind="stable")[:, :9]
+    assert np.array_equal(i.numpy(), order.astype(np.int32) + 100)
+    assert np.array_equal(v.numpy(), np.take_along_axis(s, order, axis=1))
+    assert i[0, :3].tolist() == [107, 140, 400]
