@@ -306,6 +306,7 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
     (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard -> gemm_nt_kernel
     (512, 125_000, 10, False),    # a 1M-row bf16 gallery on 8 GPUs: enough 256 x 256 tiles -> gemm256_kernel<false>, f32 out
     (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU: 8 tiles of 245 rows per workgroup
+    (16, 2_000_000, 10, True),    # 2M rows (16.9 GB): > 4096 level-0 candidates per query -> register select level + fused final
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):
     _full_size_check(dev, B, N, k, fp8, seed=B + N)
