@@ -68,7 +68,14 @@ __global__ __launch_bounds__(256, WGPC) void knn_scores_kernel(
   if (len <= 0) return;
   const int ntile = (len + KNN_TR - 1) / KNN_TR;
   const int th_nom = (len + ntile - 1) / ntile;
-  const int nk = row_bytes >> 7;
+  // K slice of this workgroup (small shards: gridDim.z > 1 slices, each into its own score slab, summed by the
+  // level-0 select in slice order — see knn_ksplit)
+  const int nk_all = row_bytes >> 7;
+  const int k_lo = (int)((long long)nk_all * blockIdx.z / gridDim.z), k_hi = (int)((long long)nk_all * (blockIdx.z + 1) / gridDim.z);
+  const int nk = k_hi - k_lo;
+  Q += (long long)k_lo * 128;
+  G += (long long)k_lo * 128;
+  S += (long long)blockIdx.z * B * ldS;
 
   for (int t = 0; t < ntile; ++t) {
     const int row0 = (int)r_begin + t * th_nom;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(
 template <int CAP>
 __global__ __launch_bounds__(256) void knn_select_stream_kernel(
     const float* __restrict__ S, int N, long long ldS, int ch,
-    float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk) {
+    float* __restrict__ out_val, int32_t* __restrict__ out_idx, int kp, int nchunk, int nslab, long long slab_stride) {
   __shared__ unsigned long long tmax[256];
   __shared__ unsigned long long wtop[4][128];
   __shared__ unsigned long long cand[CAP];
@@ -343,6 +350,25 @@ __global__ __launch_bounds__(256) void knn_select_stream_kernel(
     // rows of S are padded to a multiple of 64 floats (ldS), so a float4 that starts inside the row stays inside it;
     // positions past `len` are masked below
     q[i] = p < len ? *reinterpret_cast<const float4*>(v + base + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // K-split shards (small N): the score is the sum of the slices' slabs, added in slice order (deterministic); the sum
+  // goes back into slab 0 so that the workspace still holds THE score matrix afterwards (vpr_knn_scores_ptr)
+  if (nslab > 1) {
+    for (int z = 1; z < nslab; ++z) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = tid * 4 + i * 1024;
+        if (p < len) {
+          const float4 t = *reinterpret_cast<const float4*>(v + z * slab_stride + base + p);
+          q[i].x += t.x; q[i].y += t.y; q[i].z += t.z; q[i].w += t.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = tid * 4 + i * 1024;
+      if (p < len) *reinterpret_cast<float4*>(const_cast<float*>(v) + base + p) = q[i];
+    }
   }
   float bv = -INFINITY;
   int bi = -1;
@@ -850,6 +876,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
 // ---------------------------------------------------------------------------------------------
 struct KnnPlan {
   int Bpad, ldS, kp, ch0;
+  int ks_max;            // score slabs the workspace holds (K-split of small shards)
   int nlevel;            // number of select levels before the final kernel
   int L[4], nchunk[4];   // input length / chunk count per level
   size_t off_S, off_cv[2], off_ci[2], off_qn, total;
@@ -875,9 +902,16 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
     ++p->nlevel;
     if (p->nchunk[p->nlevel - 1] == 1) break;
   }
+  // Small shards: fewer 16-row blocks than workgroup slots, and the 132 dependent K-steps of a row tile are a latency
+  // chain (1k rows: 88 us for 17 MB).  The K range is then split over up to 8 workgroups per row tile, each writing its
+  // own score slab; the level-0 select adds the slabs.  512 = the resident grid the score kernel is sized for.
+  {
+    const int nwg0 = (N + 15) / 16 < 512 ? (N + 15) / 16 : 512;
+    p->ks_max = 512 / nwg0 < 8 ? 512 / nwg0 : 8;
+  }
   size_t off = 0;
   p->off_S = off;
-  off += align_up((size_t)B * p->ldS * sizeof(float), 256);
+  off += align_up((size_t)B * p->ldS * sizeof(float) * p->ks_max, 256);
   const size_t cand = (size_t)B * p->nchunk[0] * p->kp;
   for (int i = 0; i < 2; ++i) {
     p->off_cv[i] = off; off += align_up(cand * sizeof(float), 256);
@@ -927,8 +961,17 @@ static bool knn_fp8_use_gemm256(int B) {
   return 4 * B >= 3 * tiles * 256;
 }
 
+static int knn_ksplit(const KnnPlan& p, int row_bytes) {
+  int ks = p.ks_max;
+  const int nk = row_bytes >> 7;
+  if (ks > nk / 8) ks = nk / 8;                 // a slice keeps at least 8 K-steps
+  return ks < 1 ? 1 : ks;
+}
+
+// ksplit_ok: the caller's select stage will add the slabs (vpr_knn_topk*); the stand-alone score entry point writes
+// the one score matrix its contract promises.
 int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_bytes, int k_for_plan,
-               hipStream_t stream) {
+               hipStream_t stream, bool ksplit_ok = false) {
   KnnPlan p;
   if (!ws) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k_for_plan, &p)) return VPR_ERR_UNSUPPORTED;
@@ -977,8 +1020,8 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   const int max_useful = (N + 15) / 16;
   if (nwg > max_useful) nwg = max_useful;
   const size_t lds = (size_t)2 * (tr + KNN_QT) * TILE_ROW_BYTES;
-  const dim3 grid(nwg, p.Bpad / KNN_QT);
   const int rb = o.fp8 ? D : D * 2;
+  const dim3 grid(nwg, p.Bpad / KNN_QT, ksplit_ok ? knn_ksplit(p, rb) : 1);
 #define VPR_KNN_LAUNCH(F8, TR, W, A)                                                                   \
   do {                                                                                                 \
     static bool attr = false;                                                                          \
@@ -1032,7 +1075,8 @@ static float knn_err_rel(int D, float gallery_norm_bound) {
 
 int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base, float* out_val,
                int32_t* out_idx, void* ws, size_t ws_bytes, hipStream_t stream,
-               float gallery_norm_bound = NORM_BOUND_BF16, int32_t* status = nullptr, int32_t* uncertified = nullptr) {
+               float gallery_norm_bound = NORM_BOUND_BF16, int32_t* status = nullptr, int32_t* uncertified = nullptr,
+               bool ksplit_scores = false) {
   if (!(gallery_norm_bound > 0.f)) return VPR_ERR_INVALID_ARG;
   const float err_rel = knn_err_rel(D, gallery_norm_bound);
   KnnPlan p;
@@ -1047,6 +1091,10 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
   long long ld = p.ldS;
   int L = N;
   const int rb = o.fp8 ? D : D * 2;
+  // slabs to add: only the stream kernel (<= 64 queries, i.e. below the GEMM crossover) splits K
+  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
+  const int nslab = (ksplit_scores && B < (genv ? atoi(genv) : 65)) ? knn_ksplit(p, rb) : 1;
+  const long long slab_stride = (long long)B * p.ldS;
   int lev = 0;
   for (; lev < p.nlevel; ++lev) {
     // the fused final kernel takes over as soon as the candidates of a query fit one workgroup
@@ -1056,10 +1104,10 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
     int32_t* oi = reinterpret_cast<int32_t*>(w + p.off_ci[lev & 1]);
     if (lev == 0 && p.kp <= 32)
       VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel<1024>, dim3(p.nchunk[0], B), dim3(256), 0, stream,
-                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0]));
+                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0], nslab, slab_stride));
     else if (lev == 0)
       VPR_TRY_LAUNCH(launch_kernel(knn_select_stream_kernel<4096>, dim3(p.nchunk[0], B), dim3(256), 0, stream,
-                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0]));
+                                   cur_v, N, ld, p.ch0, ov, oi, p.kp, p.nchunk[0], nslab, slab_stride));
     else
       VPR_TRY_LAUNCH(launch_kernel(knn_select_kernel, dim3(p.nchunk[lev], B), dim3(256), 0, stream,
                                    cur_v, cur_i, L, ld, ov, oi, p.kp, p.nchunk[lev]));
@@ -1186,10 +1234,10 @@ static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int in
   if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
   if (!knn_plan(B, N, D, k, &p)) return VPR_ERR_UNSUPPORTED;
   if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
-  const int st = knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream));
+  const int st = knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream), true);
   if (st != VPR_OK) return st;
   return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
-                    static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified);
+                    static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified, true);
 }
 
 extern "C" int vpr_knn_topk(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
