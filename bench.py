@@ -371,8 +371,11 @@ def main():
         except Exception:                                       # noqa: BLE001  a broken summary only costs the traffic figure
             traffic, traffic_source = None, None
 
+    whole_call = a.knn_dtype == "fp8" or n_shard <= VPRGeoPosePipeline.SPLIT_TIMING_MIN_ROWS
     if bq <= 64 or a.knn_dtype == "fp8":
-        roofline = {"bound": "hbm", "kernel": score_kernel if a.knn_dtype == "bf16" else f"vpr_knn_topk_fp8 (quantise queries + {score_kernel} + select)",
+        roofline = {"bound": "hbm", "kernel": score_kernel if not whole_call else
+                    (f"vpr_knn_topk_fp8 (quantise queries + {score_kernel} + select)" if a.knn_dtype == "fp8" else
+                     f"vpr_knn_topk whole call ({score_kernel}, K-split for this small shard, + select)"),
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}

@@ -26,6 +26,8 @@ class StepOutput:
 
 
 class VPRGeoPosePipeline:
+    SPLIT_TIMING_MIN_ROWS = 4096       # below: the score stage may be K-split (vpr_knn_topk only): time the whole call
+
     def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10,
                  overlap_head: Optional[bool] = None):
         self.extractor, self.head, self.gallery, self.k = extractor, head, gallery, k
@@ -55,7 +57,7 @@ class VPRGeoPosePipeline:
                 pose = self.head(desc)
             desc.record_stream(side)
         q_all = g.gather_queries(desc16)
-        if self.knn_events is not None and getattr(g, "scales", None) is None:
+        if self.knn_events is not None and getattr(g, "scales", None) is None and g.rows.shape[0] > self.SPLIT_TIMING_MIN_ROWS:
             # same kernels as ShardedGallery.search, with HIP events around the score kernel
             B = q_all.shape[0]
             ws = ops.knn_workspace(B, g.rows.shape[0], q_all.shape[1], self.k, q_all.device)
@@ -70,7 +72,8 @@ class VPRGeoPosePipeline:
                 vs, is_ = all_gather_topk(v, i, g.world, g.group)
                 v, i = ops.topk_merge(vs, is_)
         elif self.knn_events is not None:
-            # fp8 shard: events around the whole local search (quantise queries + scores + select)
+            # fp8 shard, or a shard small enough for the K-split form of the score stage (which only the whole
+            # vpr_knn_topk call runs): events around the whole local search
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             v, i = g._local(q_all, self.k)
