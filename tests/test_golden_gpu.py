@@ -315,3 +315,49 @@ def test_angle_validation_entry_point(dev, tmp_path, capsys):
                                                         360 - np.abs(csv["predicted_angle"] - csv["true_angle"])))
     t = pd.read_csv(tmp_path / "test_pred.csv")
     assert list(t.columns) == ["filename", "predicted_angle_degrees"] and t["filename"].tolist() == ["img_0010.png", "img_0011.png"]
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_retrieval_evaluation_entry_points(dev, tmp_path, fp8):
+    """build_gallery_from_images + calculate_retrieval_scores (the north-star retrieval stage behind the validation
+    scripts' CSV / image-directory conventions): every validation image is a lightly perturbed copy of one gallery image,
+    so the best match, the transferred (lat, lon, angle), final_loss, MAAE and the Recall figures are known in closed form."""
+    import pandas as pd
+    from PIL import Image
+    from vpr_amd import evaluate, modules
+    rng = np.random.default_rng(21)
+    gdir, vdir = tmp_path / "images_train", tmp_path / "images_val"
+    gdir.mkdir(), vdir.mkdir()
+    n_g = 20
+    gnames = [f"img_{i:04d}.png" for i in range(n_g)]
+    imgs = [rng.integers(0, 256, (224, 224, 3), dtype=np.uint8) for _ in range(n_g)]
+    for n, im in zip(gnames, imgs):
+        Image.fromarray(im).save(gdir / n)
+    lat = 219000 + 100.0 * np.arange(n_g)
+    lon = 143000 + 50.0 * np.arange(n_g)
+    ang = (17.0 * np.arange(n_g)) % 360
+    pd.DataFrame({"filename": gnames, "timestamp": "t", "latitude": lat, "longitude": lon, "angle": ang,
+                  "Region_ID": np.arange(n_g) // 5}).to_csv(tmp_path / "labels_train.csv", index=False)
+    src = [3, 11, 0, 19, 7, 12]
+    vnames = [f"img_{i:04d}.png" for i in range(len(src))]
+    for n, s in zip(vnames, src):
+        noisy = np.clip(imgs[s].astype(np.int16) + rng.integers(-3, 4, imgs[s].shape), 0, 255).astype(np.uint8)
+        Image.fromarray(noisy).save(vdir / n)
+    off = np.array([[3.0, -4.0]] * len(src))
+    pd.DataFrame({"filename": vnames, "timestamp": "t", "latitude": lat[src] + off[:, 0], "longitude": lon[src] + off[:, 1],
+                  "angle": (ang[src] + 5.0) % 360, "Region_ID": np.array(src) // 5}).to_csv(tmp_path / "labels_val.csv", index=False)
+    torch.manual_seed(1)
+    ext = modules.DinoV2Salad("vit_small")
+    for p in ext.aggregator.parameters():
+        if p.dim() > 0:
+            torch.nn.init.normal_(p, std=0.05)
+    n = evaluate.build_gallery_from_images(ext, str(tmp_path / "labels_train.csv"), str(gdir), str(tmp_path / "gal"), fp8=fp8, batch_size=8)
+    assert n == n_g
+    res = evaluate.calculate_retrieval_scores(ext, str(tmp_path / "gal"), str(tmp_path / "labels_val.csv"), str(vdir), k=5,
+                                              tau=10.0, batch_size=4, verbose=False)
+    assert res["topk_indices"][:, 0].tolist() == src                          # the perturbed copy finds its source
+    assert np.allclose(res["pose"][:, 0], lat[src]) and np.allclose(res["pose"][:, 1], lon[src]) and np.allclose(res["pose"][:, 2], ang[src])
+    assert res["final_loss"] == pytest.approx(0.5 * (9.0 + 16.0))             # 0.5 * (sum dlat^2 + sum dlon^2) / N
+    assert res["maae"] == pytest.approx(5.0)
+    assert res["recall_at_1_tau"] == 1.0 and res["recall_at_1_region"] == 1.0 and res["uncertified_queries"] == 0
+    assert (res["topk_scores"][:, 0] > res["topk_scores"][:, 1]).all()

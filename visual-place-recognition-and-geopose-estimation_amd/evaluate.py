@@ -280,3 +280,79 @@ def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, 
             if test_csv:
                 reports.write_angle_test_csv(test_csv, tnames, tpred)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Retrieval-based geopose (north-star stage; the reference has no retrieval — SURVEY fact 3, §8f-2): the same CSV + image
+# directory conventions as the validation scripts, with the gallery built from the training split.
+@torch.no_grad()
+def build_gallery_from_images(extractor: DinoV2Salad, csv_path: str, image_dir: str, out_dir: str, *, fp8: bool = False,
+                              batch_size: int = 64, device: str = "cuda", image_size: int = 224) -> int:
+    """labels CSV (`filename,timestamp,latitude,longitude,angle,Region_ID`, cleaned_dataset_files/labels_train.csv:1) +
+    images -> on-disk gallery (gallery.save_gallery: bf16 rows, or e4m3 rows + per-row scales with fp8=True).
+    Preprocessing = the DINOv2+SALAD validation transform (dinov2salad_validation.py:18-22).  Returns the row count."""
+    from . import gallery as G, ops
+    dev = torch.device(device)
+    extractor = extractor.to(dev).to(torch.bfloat16).eval()
+    df = _existing_rows(csv_path, image_dir)
+    names = df["filename"].tolist()
+    prep = ResizeNormalize(image_size, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
+    desc = torch.empty((len(names), 8448), dtype=torch.float32, device=dev)
+    for idxs, part in _batches_by_size(image_dir, names, batch_size):
+        desc[torch.tensor(idxs, device=dev)] = extractor(prep(_load_batch(image_dir, part, dev)))
+    labels = df[list(G.LABEL_COLUMNS)].to_numpy(dtype=np.float64)
+    if fp8:
+        rows, scales = ops.quantize_fp8_rows(desc)
+        G.save_gallery(out_dir, rows, labels, scales=scales, filenames=names)
+    else:
+        G.save_gallery(out_dir, desc.to(torch.bfloat16), labels, filenames=names)
+    return len(names)
+
+
+@torch.no_grad()
+def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv_path: str, image_dir: str, *, k: int = 10,
+                               tau: float = 25.0, mode: str = "top1", batch_size: int = 64, device: str = "cuda",
+                               image_size: int = 224, rank: int = 0, world: int = 1, group=None, verbose: bool = True) -> dict:
+    """Validation split through descriptor -> sharded cosine top-k -> label transfer:
+      pose      (lat, lon, angle) of the best match, or the softmax-weighted mean of the k matches (gallery.label_transfer);
+      final_loss on lat/lon with the validation scripts' formula (dinov2salad_validation.py:101), MAAE on the angle
+                (swin_angle_finetuning_gemini.py:131-146);
+      Recall@1 / Recall@k with positives = gallery rows within `tau` label units of the query (Euclidean on the projected
+                lat/lon) and, separately, rows of the same Region_ID.
+    With world > 1 every rank runs this with its shard (load_gallery_shard) and its share of the queries is gathered by
+    ShardedGallery.search_local_queries; the metrics are then those of this rank's queries."""
+    from . import gallery as G
+    from .retrieval import ShardedGallery
+    dev = torch.device(device)
+    extractor = extractor.to(dev).to(torch.bfloat16).eval()
+    shard = G.load_gallery_shard(gallery_dir, dev, rank, world)
+    sg = ShardedGallery(shard.rows, shard.n_total, rank, world, group=group, scales=shard.scales)
+    df = _existing_rows(val_csv_path, image_dir)
+    names = df["filename"].tolist()
+    prep = ResizeNormalize(image_size, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
+    kk = min(k, shard.n_total)
+    vals = torch.empty((len(names), kk), dtype=torch.float32, device=dev)
+    idx = torch.empty((len(names), kk), dtype=torch.int32, device=dev)
+    for idxs, part in _batches_by_size(image_dir, names, batch_size):
+        _, d16 = extractor.features(prep(_load_batch(image_dir, part, dev)), want_bf16=True)
+        v, i = sg.search_local_queries(d16, kk)
+        sel = torch.tensor(idxs, device=dev)
+        vals[sel], idx[sel] = v, i
+    labels = shard.labels
+    pose = G.label_transfer(vals, idx, labels, mode=mode)
+    targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float64)
+    top = idx.cpu().numpy()
+    pos_d = G.positives_by_distance(targets, labels[:, :2], tau)
+    pos_r = G.positives_by_region(df["Region_ID"].to_numpy(), labels[:, 3])
+    res = {"filenames": names, "topk_scores": vals.cpu().numpy(), "topk_indices": top, "pose": pose,
+           "final_loss": postproc.final_loss(pose[:, :2], targets),
+           "maae": postproc.mean_absolute_angular_error(pose[:, 2], df["angle"].to_numpy(dtype=np.float64)),
+           "recall_at_1_tau": postproc.recall_at_k(top[:, :1], pos_d), f"recall_at_{kk}_tau": postproc.recall_at_k(top, pos_d),
+           "recall_at_1_region": postproc.recall_at_k(top[:, :1], pos_r),
+           "uncertified_queries": sg.uncertified_queries()}
+    if verbose:
+        print(f"final_loss: {res['final_loss']}")
+        print(f"Mean Absolute Angular Error (MAAE): {res['maae']:.4f} degrees")
+        print(f"Recall@1 (tau={tau}): {res['recall_at_1_tau']:.4f}  Recall@{kk}: {res[f'recall_at_{kk}_tau']:.4f}  "
+              f"Recall@1 (Region_ID): {res['recall_at_1_region']:.4f}")
+    return res
