@@ -876,7 +876,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(
 // ---------------------------------------------------------------------------------------------
 struct KnnPlan {
   int Bpad, ldS, kp, ch0;
-  int ks_max;            // score slabs the workspace holds (K-split of small shards)
+  int ks_max;            // score slabs the workspace holds (K-split of shards below 106k rows)
+  int nrt;               // row tiles of the K-split form
   int nlevel;            // number of select levels before the final kernel
   int L[4], nchunk[4];   // input length / chunk count per level
   size_t off_S, off_cv[2], off_ci[2], off_qn, total;
@@ -902,12 +903,17 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
     ++p->nlevel;
     if (p->nchunk[p->nlevel - 1] == 1) break;
   }
-  // Small shards: fewer 16-row blocks than workgroup slots, and the 132 dependent K-steps of a row tile are a latency
-  // chain (1k rows: 88 us for 17 MB).  The K range is then split over up to 8 workgroups per row tile, each writing its
-  // own score slab; the level-0 select adds the slabs.  512 = the resident grid the score kernel is sized for.
+  // Small and medium shards (N < 106k rows: fewer 208-row tiles than the 512 resident workgroup slots).  Cutting the rows
+  // finer to fill the chip multiplies the query traffic (every workgroup re-stages all 64 query rows: at 6k rows 16-row
+  // tiles read 431 MB of queries for 108 MB of gallery) and leaves each tile a 132-step latency chain.  Instead: tall row
+  // tiles (as few as fill the slots together with the K split, at least min(32, N/16)), and the K range of a tile split
+  // over up to 16 workgroups, each writing its own score slab; the level-0 select adds the slabs.
   {
-    const int nwg0 = (N + 15) / 16 < 512 ? (N + 15) / 16 : 512;
-    p->ks_max = 512 / nwg0 < 8 ? 512 / nwg0 : 8;
+    const int by208 = (N + 207) / 208, by16 = (N + 15) / 16;
+    const int fill = by16 < 32 ? by16 : 32;
+    p->nrt = by208 > fill ? by208 : fill;
+    int ks = 512 / p->nrt;
+    p->ks_max = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
   }
   size_t off = 0;
   p->off_S = off;
@@ -1021,7 +1027,9 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   if (nwg > max_useful) nwg = max_useful;
   const size_t lds = (size_t)2 * (tr + KNN_QT) * TILE_ROW_BYTES;
   const int rb = o.fp8 ? D : D * 2;
-  const dim3 grid(nwg, p.Bpad / KNN_QT, ksplit_ok ? knn_ksplit(p, rb) : 1);
+  const int ksplit = ksplit_ok ? knn_ksplit(p, rb) : 1;
+  if (ksplit > 1) nwg = p.nrt;                    // tall tiles: the K split supplies the parallelism
+  const dim3 grid(nwg, p.Bpad / KNN_QT, ksplit);
 #define VPR_KNN_LAUNCH(F8, TR, W, A)                                                                   \
   do {                                                                                                 \
     static bool attr = false;                                                                          \
