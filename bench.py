@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 D_DESC = 8448
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense fp8 (block-scaled f8f6f4 MFMA), same guide
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -123,7 +124,7 @@ def _avg_ms(fn, n=10, warm=2):
 def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
     """Roofline rows of the other hand-written stages (BASELINE configs 2, 4, 5), each timed on its own after the timed
     region: algorithmic FLOPs / bytes over the average device time of the whole entry point."""
-    from vpr_amd import ops
+    from vpr_amd import _lib, ops
     from vpr_amd.gallery import GalleryShard
     from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
     rows = {}
@@ -166,6 +167,24 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
         rows["knn_topk_bf16_graph_replay"] = dict(entry="GraphedRetrieval (hipGraph: scores + select + final)",
                                                   shape=f"B={B} N={N}", **hbm(by, ms_g))
         del gr, ws
+        # what ONE rank of an 8-GPU job runs per step on this gallery: the 512 all-gathered queries x its N/8-row shard
+        # (MFMA GEMM route: gemm256_kernel, 2 K slices)
+        if N >= 8 * 1024:
+            Bg, Ns = 8 * B, N // 8
+            qg = torch.nn.functional.normalize(torch.randn(Bg, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
+            sh = shard_bf16[:Ns]
+            ws = ops.knn_workspace(Bg, Ns, D_DESC, a.k, dev)
+            ev = []
+            ms = _avg_ms(lambda: ops.knn_topk(qg, sh, a.k, 0, ws, score_events=ev))
+            torch.cuda.synchronize()
+            ms_k = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+            fl = 2.0 * Bg * Ns * D_DESC
+            rows["knn_topk_bf16_gathered_8gpu_shard"] = {
+                "entry": "vpr_knn_topk_scores_stage + vpr_knn_topk_select_stage", "shape": f"B={Bg} N={Ns} D={D_DESC} k={a.k}",
+                "kernel": _lib.lib().vpr_knn_scores_kernel_name(0, Bg, Ns).decode(), "bound": "mfma",
+                "achieved": fl / ms_k / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / ms_k / 1e9 / MFMA_BF16_PEAK_TFLOPS, "ms": ms_k, "whole_call_ms": ms, "algorithmic_flops": fl}
+            del ws, qg
     # e4m3 gallery, 1M rows on one GPU (config 5's arithmetic and bytes; 8 GPUs would hold 125k rows each)
     N8 = a.fp8_rows
     if N8 > 0:
@@ -188,7 +207,24 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
         ms_g = _avg_ms(lambda: gr(qb), n=5)
         rows["retrieval_fp8_graph_replay"] = dict(entry="GraphedRetrieval (hipGraph: quantise queries + scores + select + final)",
                                                   shape=f"B={B} N={N8} e4m3", **hbm(by, ms_g))
-        del gr, g8, gs, ws
+        del gr, ws
+        # config 5 as ONE rank of the 8-GPU job runs it: 512 gathered queries x a 125k-row e4m3 shard (gemm256_kernel<true>)
+        if N8 >= 8 * 1024:
+            Bg, Ns = 8 * B, N8 // 8
+            q8g, qsg = ops.quantize_fp8_rows(torch.nn.functional.normalize(torch.randn(Bg, D_DESC, device=dev, generator=g), dim=1))
+            ws = ops.knn_workspace(Bg, Ns, D_DESC, a.k, dev)
+            ev = []
+            ms = _avg_ms(lambda: ops.knn_topk_fp8(q8g, qsg, g8[:Ns], gs[:Ns], a.k, 0, ws, score_events=ev), n=5)
+            torch.cuda.synchronize()
+            ms_k = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+            fl = 2.0 * Bg * Ns * D_DESC
+            rows["knn_topk_fp8_gathered_8gpu_shard"] = {
+                "entry": "vpr_knn_topk_scores_stage + vpr_knn_topk_select_stage (e4m3)", "shape": f"B={Bg} N={Ns} D={D_DESC} k={a.k}",
+                "kernel": _lib.lib().vpr_knn_scores_kernel_name(1, Bg, Ns).decode(), "bound": "mfma",
+                "achieved": fl / ms_k / 1e9, "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / ms_k / 1e9 / MFMA_FP8_PEAK_TFLOPS, "ms": ms_k, "whole_call_ms": ms, "algorithmic_flops": fl}
+            del ws
+        del g8, gs
     return rows
 
 
@@ -371,21 +407,20 @@ def main():
         except Exception:                                       # noqa: BLE001  a broken summary only costs the traffic figure
             traffic, traffic_source = None, None
 
-    whole_call = a.knn_dtype == "fp8" or n_shard <= VPRGeoPosePipeline.SPLIT_TIMING_MIN_ROWS
-    if bq <= 64 or a.knn_dtype == "fp8":
-        roofline = {"bound": "hbm", "kernel": score_kernel if not whole_call else
-                    (f"vpr_knn_topk_fp8 (quantise queries + {score_kernel} + select)" if a.knn_dtype == "fp8" else
-                     f"vpr_knn_topk whole call ({score_kernel}, K-split for this small shard, + select)"),
+    # knn_avg_s = the score stage alone (HIP events between the two stages of vpr_knn_topk*, same kernels as the one-call form)
+    if bq <= 64:
+        roofline = {"bound": "hbm", "kernel": score_kernel,
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}
     else:
-        # more than one 64-query tile per shard scan (multi-GPU: all-gathered queries): vpr_knn_scores runs the
-        # score tile as an MFMA GEMM (gemm_nt_kernel) — one gallery pass per 128 queries, 2*bq FLOP per gallery byte
+        # more than one 64-query tile per shard scan (multi-GPU: all-gathered queries): the score tile runs as an MFMA
+        # GEMM (gemm256_kernel / gemm_nt_kernel, K-split for small shards) — 2*bq FLOP per gallery row element
         flops = 2.0 * bq * n_shard * D_DESC
+        peak = MFMA_FP8_PEAK_TFLOPS if a.knn_dtype == "fp8" else MFMA_BF16_PEAK_TFLOPS
         roofline = {"bound": "mfma", "kernel": f"{score_kernel} (score tile, query batch > 64)",
-                    "achieved": flops / knn_avg_s / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": flops / knn_avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                    "achieved": flops / knn_avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": flops / knn_avg_s / 1e12 / peak, "traffic": None,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_flops": flops}
 
     if rank == 0:

@@ -179,6 +179,19 @@ int vpr_knn_topk_fp8_checked(const uint8_t* q, const float* q_scale, const uint8
                              float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
                              float gallery_norm_bound, int32_t* status, int32_t* uncertified, void* stream);
 
+/* vpr_knn_topk[_fp8]_checked as two calls — the HBM-bound score stage and the latency-bound tail (level-0 select,
+ * exact rescoring, ordering, certificate) — for callers that record events or enqueue other work between them
+ * (bench.py times the score kernel this way inside the end-to-end step).  Same kernels and results as the one-call
+ * form; between the two calls the workspace holds the scores in a private layout (K-slice slabs for small shards and
+ * for gathered batches; use vpr_knn_scores for a plain score matrix).  bf16: is_fp8 = 0, scales NULL. */
+int vpr_knn_topk_scores_stage(const void* q, const float* q_scale, const void* gallery, const float* gallery_scale,
+                              int is_fp8, int B, int N, int D, int k, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int vpr_knn_topk_select_stage(const void* q, const float* q_scale, const void* gallery, const float* gallery_scale,
+                              int is_fp8, int B, int N, int D, int k, int index_base, float* out_val,
+                              int32_t* out_idx, void* workspace, size_t workspace_bytes, float gallery_norm_bound,
+                              int32_t* status, int32_t* uncertified, void* stream);
+
 /* Exhaustive form (the fallback for status-2 queries): every score computed exactly (f64 accumulation, one wave
  * per gallery row), then the same selection — exact by construction, ~B gallery passes of f64 work: meant for a
  * handful of queries.  q / gallery: bf16 (is_fp8 = 0, scales NULL) or e4m3 bytes with per-row scales.

@@ -303,13 +303,70 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
     (64, 125_000, 10, True),      # config 5, one 8-way shard of the 1M gallery: one 244-row tile per workgroup (256-row form)
     (512, 125_000, 10, True),     # config 5 on 8 GPUs: the all-gathered 512-query batch -> gemm256_kernel<true>
     (320, 60_000, 10, True),      # a 256-row tile would be 62 % full -> gemm_nt_fp8_kernel (128 x 128 tiles)
-    (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard -> gemm_nt_kernel
+    (512, 12_500, 10, False),     # config 3 on 8 GPUs: 512 gathered queries x one shard: 98 tiles -> gemm256_kernel<false>, 2 K slices
+    (256, 25_000, 10, False),     # config 3 on 4 GPUs: same 98 tiles, 2 K slices
+    (512, 12_500, 10, True),      # e4m3 form of the split-K GEMM
     (512, 125_000, 10, False),    # a 1M-row bf16 gallery on 8 GPUs: enough 256 x 256 tiles -> gemm256_kernel<false>, f32 out
     (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU: 8 tiles of 245 rows per workgroup
     (16, 2_000_000, 10, True),    # 2M rows (16.9 GB): > 4096 level-0 candidates per query -> register select level + fused final
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):
     _full_size_check(dev, B, N, k, fp8, seed=B + N)
+
+
+@pytest.mark.parametrize("B,N,fp8", [(64, 3000, False), (64, 30000, True), (300, 5000, False), (512, 6378, True)])
+def test_knn_two_stage_call_equals_one_call(dev, B, N, fp8):
+    """vpr_knn_topk_scores_stage + vpr_knn_topk_select_stage (what the pipeline runs when it times the score stage) ==
+    vpr_knn_topk[_fp8]_checked, for the K-split stream form, the plain stream form and both GEMM routes."""
+    from vpr_amd import ops
+    D, k = 8448, 10
+    g = torch.Generator(device=dev).manual_seed(B + N)
+    gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1)
+    ev = []
+    if fp8:
+        G, gs = ops.quantize_fp8_rows(gal)
+        Q, qs = ops.quantize_fp8_rows(q)
+        v1, i1 = ops.knn_topk_fp8(Q, qs, G, gs, k, 7)
+        v2, i2 = ops.knn_topk_fp8(Q, qs, G, gs, k, 7, score_events=ev)
+    else:
+        G, Q = gal.to(torch.bfloat16), q.to(torch.bfloat16)
+        v1, i1 = ops.knn_topk(Q, G, k, 7)
+        v2, i2 = ops.knn_topk(Q, G, k, 7, score_events=ev)
+    torch.cuda.synchronize()
+    assert torch.equal(v1, v2) and torch.equal(i1, i2)
+    assert len(ev) == 1 and ev[0][0].elapsed_time(ev[0][1]) > 0
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_knn_gemm_split_k_equals_unsplit(dev, monkeypatch, fp8):
+    """Gathered batch against a shard with fewer than 256 score tiles: the 256 x 256-tile GEMM splits K into slabs the
+    level-0 select adds.  Same final answer as the unsplit routes (exact rescoring), and the summed score matrix agrees
+    with the unsplit one to f32 summation-order noise."""
+    from vpr_amd import ops, _lib
+    B, N, D, k = 512, 6378, 8448, 10
+    assert _lib.lib().vpr_knn_scores_kernel_name(int(fp8), B, N).decode() == f"vpr::gemm256_kernel<{'true' if fp8 else 'false'}>"
+    g = torch.Generator(device=dev).manual_seed(77)
+    gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    pos = torch.randint(0, N, (B,), device=dev, generator=g)
+    q = torch.nn.functional.normalize(gal[pos] + 0.1 * torch.randn(B, D, device=dev, generator=g), dim=1)
+    if fp8:
+        G, gs = ops.quantize_fp8_rows(gal)
+        Q, qs = ops.quantize_fp8_rows(q)
+        call = lambda ws: ops.knn_topk_fp8(Q, qs, G, gs, k, 0, ws)
+    else:
+        G, Q = gal.to(torch.bfloat16), q.to(torch.bfloat16)
+        call = lambda ws: ops.knn_topk(Q, G, k, 0, ws)
+    outs = []
+    for ks in ("0", "1"):
+        monkeypatch.setenv("VPR_KNN_GEMM_KSPLIT", ks)
+        ws = ops.knn_workspace(B, N, D, k, dev)
+        ws.zero_()
+        v, i = call(ws)
+        outs.append((ops.knn_scores_view(ws, B, N, D, k).clone(), v, i))
+    (s0, v0, i0), (s1, v1, i1) = outs
+    assert (s0 - s1).abs().max().item() < 2e-6 * max(s0.abs().max().item(), 1.0)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1) and torch.equal(i1[:, 0].long(), pos)
 
 
 # ----------------------------------------------------------------- certification of the exactness contract

@@ -59,6 +59,10 @@ PROTOTYPES = {
     "vpr_knn_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_knn_select": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_topk_scores_stage": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_size_t, c_void_p]),
+    "vpr_knn_topk_select_stage": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
     "vpr_knn_scores_kernel_name": (c_char_p, [c_int, c_int, c_int]),
     "vpr_knn_scores_ptr": (c_void_p, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "vpr_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -118,7 +118,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
         dst[h][j] = G2_BM * TILE_ROW_BYTES + row0 * TILE_ROW_BYTES;
       }
     }
-  const int nk = (K * ES) >> 7;                          // 128 bytes of every row per K-tile
+  // K-tiles of this workgroup: all of them, or — split-K (gridDim.y slices: kNN score tiles of shards too small to give
+  // 256 tiles) — slice blockIdx.y, written to its own output slab (pr.slab_stride elements apart; the consumer adds them)
+  const int nk_all = (K * ES) >> 7;                      // 128 bytes of every row per K-tile
+  const int k_lo = (int)((long long)nk_all * blockIdx.y / gridDim.y);
+  const int nk = (int)((long long)nk_all * (blockIdx.y + 1) / gridDim.y) - k_lo;
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) src[h][j] += (long long)k_lo * 128;
   auto issue = [&](int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1 (kt clamped: dummy tail)
     const int kc = kt < nk ? kt : nk - 1;
     char* base = smem + (kc & 1) * G2_BUF_BYTES;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
       const int m = m0 + (lr >> 6) * 128 + qi * 64 + (lr & 63);
       const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * pitch + chunk * 16);
       if (m >= M || n >= N) continue;
-      char* dstp = reinterpret_cast<char*>(pr.C) + ((long long)m * pr.ldc + n) * es;
+      char* dstp = reinterpret_cast<char*>(pr.C) + ((long long)blockIdx.y * pr.slab_stride + (long long)m * pr.ldc + n) * es;
       if (n + epc <= N && wide) {
         *reinterpret_cast<uint4*>(dstp) = v;
       } else {                                         // ragged last chunk of the row
@@ -313,6 +321,8 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   g.tiles_m = (g.M + G2_BM - 1) / G2_BM;
   g.tiles_n = (g.N + G2_BN - 1) / G2_BN;
   g.a_scale = g.w_scale = nullptr;
+  const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
+  if (ksplit > 1 && (g.bias != nullptr || g.relu || g.K / 64 < 2 * ksplit)) return VPR_ERR_UNSUPPORTED;   // slabs are linear partial sums
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -320,19 +330,21 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
       return VPR_ERR_LAUNCH;
     attr = true;
   }
-  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g));
+  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
   return VPR_OK;
 }
 
 // e4m3 operands with per-row scales, f32 out: C[m][n] = a_scale[m] * w_scale[n] * sum_k A[m][k] W[n][k]; K % 128 == 0, K >= 256.
 int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
-                       float* C, int ldc, int M, int N, int K, hipStream_t stream) {
+                       float* C, int ldc, int M, int N, int K, hipStream_t stream, int ksplit, long long slab_stride) {
   if (!A || !W || !C || !a_scale || !w_scale || M <= 0 || N <= 0 || K <= 0) return VPR_ERR_INVALID_ARG;
+  if (ksplit < 1) ksplit = 1;
+  if (K / 128 < 2 * ksplit) return VPR_ERR_UNSUPPORTED;
   if ((K % 128) || K < 256 || lda < K || ldw < K || ldc < N || (lda % 16) || (ldw % 16) || (ldc % 4)) return VPR_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C)) & 15)
     return VPR_ERR_UNSUPPORTED;
   GemmProblem g{reinterpret_cast<const uint16_t*>(A), lda, 0, 0, reinterpret_cast<const uint16_t*>(W), ldw, nullptr, 0,
-                C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale};
+                C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale, ksplit, slab_stride};
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -340,7 +352,7 @@ int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const ui
       return VPR_ERR_LAUNCH;
     attr = true;
   }
-  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<true>, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g));
+  VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<true>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
   return VPR_OK;
 }
 

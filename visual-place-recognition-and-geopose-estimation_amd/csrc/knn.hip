@@ -914,6 +914,12 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
     p->nrt = by208 > fill ? by208 : fill;
     int ks = 512 / p->nrt;
     p->ks_max = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+    // gathered batches (> 64 queries) on the 256 x 256-tile GEMM: K slices until its one-per-CU workgroups fill 256 CUs
+    if (B > KNN_QT) {
+      const long long tiles = (long long)((B + 255) / 256) * ((N + 255) / 256);
+      ks = tiles >= 256 ? 1 : (int)(256 / tiles);
+      p->ks_max = ks > 4 ? 4 : ks;
+    }
   }
   size_t off = 0;
   p->off_S = off;
@@ -974,6 +980,30 @@ static int knn_ksplit(const KnnPlan& p, int row_bytes) {
   return ks < 1 ? 1 : ks;
 }
 
+// Which kernel scores a [B] x [N] problem, and into how many K-slice slabs (the level-0 select adds them).  One rule,
+// used by the score stage, the select stage and vpr_knn_scores_kernel_name.
+enum KnnRoute { ROUTE_STREAM, ROUTE_GEMM128, ROUTE_GEMM256 };
+static KnnRoute knn_route(const KnnPlan& p, bool fp8, int B, int N, int D, bool ksplit_ok, int* nslab) {
+  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the stream / GEMM crossover
+  const int gemm_min_b = genv ? atoi(genv) : 65;
+  const int rb = fp8 ? D : D * 2;
+  *nslab = 1;
+  if (B < gemm_min_b) {                                 // streaming kernel; shards below 106k rows split K over tall tiles
+    if (ksplit_ok) *nslab = knn_ksplit(p, rb);
+    return ROUTE_STREAM;
+  }
+  if (!knn_fp8_use_gemm256(B) || (fp8 && D < 256)) return ROUTE_GEMM128;
+  // 256 x 256 tiles, one workgroup per CU: with the K split a 512 x 12.5k problem (98 tiles) runs as 196 workgroups.
+  // Without it (stand-alone score entry point, or VPR_KNN_GEMM_KSPLIT=0) bf16 needs >= 256 tiles to beat the 128 x 128
+  // kernel's 4x as many workgroups.
+  const char* kenv = getenv("VPR_KNN_GEMM_KSPLIT");
+  int ks = (ksplit_ok && B > KNN_QT && !(kenv && !atoi(kenv))) ? knn_ksplit(p, rb) : 1;
+  const long long tiles = (long long)((B + 255) / 256) * ((N + 255) / 256);
+  if (!fp8 && tiles * ks < 192) return ROUTE_GEMM128;
+  *nslab = ks;
+  return ROUTE_GEMM256;
+}
+
 // ksplit_ok: the caller's select stage will add the slabs (vpr_knn_topk*); the stand-alone score entry point writes
 // the one score matrix its contract promises.
 int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_bytes, int k_for_plan,
@@ -989,24 +1019,24 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // towards a compute-bound GEMM: the streaming kernel makes one gallery pass per 64 queries, the
   // 128x128-tile MFMA GEMM one per 128.  Measured, stream vs GEMM: 128 x 50k 367 / 222 us,
   // 192 x 33k 406 / 300, 256 x 25k 477 / 185, 512 x 12.5k 702 / 151 (scripts/knn_b_sweep.py).
-  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the crossover
-  const int gemm_min_b = genv ? atoi(genv) : 65;
-  // e4m3, >= 384 gathered queries (512 at 8 GPUs): the 256 x 256-tile kernel with its LDS-DMA stream kept in flight across
-  // barriers (gemm256.hip, fp8 form); a 128-256-query batch would leave half of such a tile row empty.
-  if (o.fp8 && B >= gemm_min_b && D >= 256 && knn_fp8_use_gemm256(B))
+  // >= 192 of every 256 gathered queries real (256 at 4 GPUs, 512 at 8): the 256 x 256-tile kernel with its LDS-DMA
+  // stream kept in flight across barriers (gemm256.hip); a 128-query batch would leave half of such a tile row empty.
+  int nslab = 1;
+  const KnnRoute route = knn_route(p, o.fp8, B, N, D, ksplit_ok, &nslab);
+  const long long slab_stride = (long long)B * p.ldS;
+  if (route == ROUTE_GEMM256 && o.fp8)
     return launch_gemm256_fp8(static_cast<const uint8_t*>(o.q), D, o.q_scale, static_cast<const uint8_t*>(o.g), D,
-                              o.g_scale, S, p.ldS, B, N, D, stream);
-  if (o.fp8 && B >= gemm_min_b)      // block-scaled fp8 MFMA GEMM (twice the bf16 rate), scales in its epilogue
+                              o.g_scale, S, p.ldS, B, N, D, stream, nslab, slab_stride);
+  if (route == ROUTE_GEMM128 && o.fp8)      // block-scaled fp8 MFMA GEMM (twice the bf16 rate), scales in its epilogue
     return launch_gemm_nt_fp8(static_cast<const uint8_t*>(o.q), D, o.q_scale, static_cast<const uint8_t*>(o.g), D,
                               o.g_scale, S, p.ldS, B, N, D, stream);
-  // bf16, same rule plus enough 256 x 256 tiles to fill the chip (a 12.5k-row shard gives 98: the 128 x 128 kernel's 392
-  // workgroups win there; a 125k-row shard gives 978)
-  if (!o.fp8 && B >= gemm_min_b && knn_fp8_use_gemm256(B) && (long long)((B + 255) / 256) * ((N + 255) / 256) >= 256) {
-    const GemmProblem g{static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr, 0,
-                        S, p.ldS, 0, B, N, D, 0, 0};
+  if (route == ROUTE_GEMM256) {
+    GemmProblem g{static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr, 0,
+                  S, p.ldS, 0, B, N, D, 0, 0};
+    g.ksplit = nslab; g.slab_stride = slab_stride;
     return launch_gemm256(g, stream);
   }
-  if (!o.fp8 && B >= gemm_min_b)
+  if (route == ROUTE_GEMM128)
     return launch_gemm_nt(static_cast<const uint16_t*>(o.q), D, 0, 0, static_cast<const uint16_t*>(o.g), D, nullptr,
                           0, S, p.ldS, 0, B, N, D, stream);
   // Tile height / residency / cache-policy variants (same arithmetic, same results); 0 is the default, the
@@ -1027,7 +1057,7 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   if (nwg > max_useful) nwg = max_useful;
   const size_t lds = (size_t)2 * (tr + KNN_QT) * TILE_ROW_BYTES;
   const int rb = o.fp8 ? D : D * 2;
-  const int ksplit = ksplit_ok ? knn_ksplit(p, rb) : 1;
+  const int ksplit = nslab;
   if (ksplit > 1) nwg = p.nrt;                    // tall tiles: the K split supplies the parallelism
   const dim3 grid(nwg, p.Bpad / KNN_QT, ksplit);
 #define VPR_KNN_LAUNCH(F8, TR, W, A)                                                                   \
@@ -1099,9 +1129,9 @@ int knn_select(const KnnOperands& o, int B, int N, int D, int k, int index_base,
   long long ld = p.ldS;
   int L = N;
   const int rb = o.fp8 ? D : D * 2;
-  // slabs to add: only the stream kernel (<= 64 queries, i.e. below the GEMM crossover) splits K
-  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
-  const int nslab = (ksplit_scores && B < (genv ? atoi(genv) : 65)) ? knn_ksplit(p, rb) : 1;
+  // slabs to add: whatever the score stage of this problem wrote
+  int nslab = 1;
+  knn_route(p, o.fp8, B, N, D, ksplit_scores, &nslab);
   const long long slab_stride = (long long)B * p.ldS;
   int lev = 0;
   for (; lev < p.nlevel; ++lev) {
@@ -1185,14 +1215,14 @@ extern "C" size_t vpr_knn_workspace_bytes(int B, int N, int D, int k) {
 }
 
 extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N) {
-  // mirrors the dispatch of knn_scores(): what a kernel trace (rocprofv3) will show for this call
-  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");
-  const int gemm_min_b = genv ? atoi(genv) : 65;
-  const bool g2 = knn_fp8_use_gemm256(B);
-  if (B >= gemm_min_b) {
-    if (is_fp8) return g2 ? "vpr::gemm256_kernel<true>" : "vpr::gemm_nt_fp8_kernel";
-    return g2 && (long long)((B + 255) / 256) * ((N + 255) / 256) >= 256 ? "vpr::gemm256_kernel<false>" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
-  }
+  // the dispatch of vpr_knn_topk* (knn_route) at the descriptor width of the path, D = 8448: what a kernel trace
+  // (rocprofv3) will show for this call
+  KnnPlan p;
+  if (!knn_plan(B, N, 8448, 10, &p)) return "";
+  int nslab = 1;
+  const KnnRoute route = knn_route(p, is_fp8 != 0, B, N, 8448, true, &nslab);
+  if (route == ROUTE_GEMM256) return is_fp8 ? "vpr::gemm256_kernel<true>" : "vpr::gemm256_kernel<false>";
+  if (route == ROUTE_GEMM128) return is_fp8 ? "vpr::gemm_nt_fp8_kernel" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
   const char* venv = getenv("VPR_KNN_VARIANT");
   const int variant = venv ? atoi(venv) : 0;
   const bool tall = variant == 3 || (variant == 0 && knn_tall_tiles(N));
@@ -1244,6 +1274,28 @@ static int knn_topk_any(const KnnOperands& o, int B, int N, int D, int k, int in
   if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
   const int st = knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream), true);
   if (st != VPR_OK) return st;
+  return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
+                    static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified, true);
+}
+
+// The two halves of vpr_knn_topk[_fp8]_checked as separate calls (same kernels, same workspace contents in between:
+// the score stage may leave K-slice slabs that only this select stage knows to add), for callers that put events or
+// other stream work between the HBM-bound score stage and the latency-bound tail.
+extern "C" int vpr_knn_topk_scores_stage(const void* q, const float* q_scale, const void* gallery,
+                                         const float* gallery_scale, int is_fp8, int B, int N, int D, int k,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
+  const KnnOperands o{q, gallery, q_scale, gallery_scale, is_fp8 != 0};
+  return knn_scores(o, B, N, D, workspace, workspace_bytes, k, static_cast<hipStream_t>(stream), true);
+}
+
+extern "C" int vpr_knn_topk_select_stage(const void* q, const float* q_scale, const void* gallery,
+                                         const float* gallery_scale, int is_fp8, int B, int N, int D, int k,
+                                         int index_base, float* out_val, int32_t* out_idx, void* workspace,
+                                         size_t workspace_bytes, float gallery_norm_bound, int32_t* status,
+                                         int32_t* uncertified, void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return VPR_ERR_INVALID_ARG;
+  const KnnOperands o{q, gallery, q_scale, gallery_scale, is_fp8 != 0};
   return knn_select(o, B, N, D, k, index_base, out_val, out_idx, workspace, workspace_bytes,
                     static_cast<hipStream_t>(stream), gallery_norm_bound, status, uncertified, true);
 }

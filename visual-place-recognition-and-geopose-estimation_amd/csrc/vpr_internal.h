@@ -19,6 +19,7 @@ struct GemmProblem {
   const uint16_t* W; int ldw; const float* bias; int relu;
   void* C; int ldc; int out_is_bf16; int M, N, K; int tiles_m, tiles_n;
   const float* a_scale; const float* w_scale;       // gemm256 fp8 form only (per-row scales of A and W); null otherwise
+  int ksplit; long long slab_stride;                // gemm256 split-K: K slices (0 / 1 = none); slice z writes C + z * slab_stride elements
 };
 constexpr int GEMM_MAX_GROUP = 3;
 int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
@@ -28,7 +29,7 @@ int launch_gemm_nt_fp8(const uint8_t* A, int lda, const float* a_scale, const ui
 int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
 // gemm256.hip, fp8 form: e4m3 operands with per-row scales, f32 out (kNN score tile of a >= 384-query gathered batch)
 int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
-                       float* C, int ldc, int M, int N, int K, hipStream_t stream);
+                       float* C, int ldc, int M, int N, int K, hipStream_t stream, int ksplit = 1, long long slab_stride = 0);
 // skinny.hip: a few rows x [N, K]^T; mode 0 bias, 1 bias+tanh-GELU, 2 accumulate into out, 3 bias+ReLU, 4 bias+erf-GELU
 int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw, const void* bias, int bias_is_bf16,
                          int mode, uint16_t* out, int ldo, int M, int N, int K, const float* stats_bias,

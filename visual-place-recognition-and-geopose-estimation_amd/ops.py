@@ -201,8 +201,10 @@ def _check_args(B: int, device, status: Optional[torch.Tensor], uncertified: Opt
 def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0,
              ws: Optional[torch.Tensor] = None, *, norm_bound: float = NORM_BOUND_BF16,
              status: Optional[torch.Tensor] = None, uncertified: Optional[torch.Tensor] = None,
-             exact_fallback: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+             exact_fallback: bool = False, score_events: Optional[list] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """q [B,D] bf16, gallery [N,D] bf16 -> (scores f32 [B,k] descending, indices int32 [B,k]).
+    score_events: a list -> the call runs as its two stages (vpr_knn_topk_scores_stage / _select_stage: same kernels,
+    same result) and appends a (start, end) pair of timing events around the score stage.
     The kernels certify each query's answer as the exact top-k (include/vpr_amd.h, "Checked forms"):
     `status` (int32 [B]) receives 0 / 1 (certified) or 2 (not certified), `uncertified` (int32 [1]) counts the 2s
     without a host sync; `norm_bound` = upper bound of the gallery row norms.  exact_fallback=True reads the status
@@ -220,12 +222,32 @@ def knn_topk(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0
     _check_args(B, q.device, status, uncertified)
     vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
-    st = _lib.lib().vpr_knn_topk_checked(_ptr(q), _ptr(gallery), B, N, D, int(k), int(index_base), _ptr(vals), _ptr(idx),
-                                         _ptr(ws), ws.numel(), float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
-    _lib.check(st, "vpr_knn_topk_checked")
+    if score_events is not None:
+        _topk_two_stage(q, None, gallery, None, B, N, D, k, index_base, vals, idx, ws, norm_bound, status, uncertified,
+                        score_events)
+    else:
+        st = _lib.lib().vpr_knn_topk_checked(_ptr(q), _ptr(gallery), B, N, D, int(k), int(index_base), _ptr(vals), _ptr(idx),
+                                             _ptr(ws), ws.numel(), float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
+        _lib.check(st, "vpr_knn_topk_checked")
     if exact_fallback:
         _exhaustive_fixup(q, None, gallery, None, k, index_base, status, vals, idx)
     return vals, idx
+
+
+def _topk_two_stage(q, q_scale, gallery, gallery_scale, B, N, D, k, index_base, vals, idx, ws, norm_bound, status,
+                    uncertified, score_events) -> None:
+    fp8 = q_scale is not None
+    args = (_ptr(q), _ptr(q_scale) if fp8 else None, _ptr(gallery), _ptr(gallery_scale) if fp8 else None, int(fp8),
+            B, N, D, int(k))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    st = _lib.lib().vpr_knn_topk_scores_stage(*args, _ptr(ws), ws.numel(), _stream())
+    e1.record()
+    _lib.check(st, "vpr_knn_topk_scores_stage")
+    score_events.append((e0, e1))
+    st = _lib.lib().vpr_knn_topk_select_stage(*args, int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(),
+                                              float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
+    _lib.check(st, "vpr_knn_topk_select_stage")
 
 
 def knn_topk_exhaustive(q: torch.Tensor, gallery: torch.Tensor, k: int, index_base: int = 0,
@@ -281,7 +303,7 @@ def quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 def knn_topk_fp8(q: torch.Tensor, q_scale: torch.Tensor, gallery: torch.Tensor, gallery_scale: torch.Tensor,
                  k: int, index_base: int = 0, ws: Optional[torch.Tensor] = None, *, norm_bound: float = NORM_BOUND_FP8,
                  status: Optional[torch.Tensor] = None, uncertified: Optional[torch.Tensor] = None,
-                 exact_fallback: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                 exact_fallback: bool = False, score_events: Optional[list] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """fp8 (e4m3 bytes + per-row f32 scale) variant of knn_topk; D % 128 == 0.  norm_bound bounds the norms of the
     DEQUANTISED gallery rows."""
     _need(q, torch.uint8, "q", 2)
@@ -299,10 +321,14 @@ def knn_topk_fp8(q: torch.Tensor, q_scale: torch.Tensor, gallery: torch.Tensor, 
     _check_args(B, q.device, status, uncertified)
     vals = torch.empty((B, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((B, k), dtype=torch.int32, device=q.device)
-    st = _lib.lib().vpr_knn_topk_fp8_checked(_ptr(q), _ptr(q_scale), _ptr(gallery), _ptr(gallery_scale), B, N, D, int(k),
-                                             int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(),
-                                             float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
-    _lib.check(st, "vpr_knn_topk_fp8_checked")
+    if score_events is not None:
+        _topk_two_stage(q, q_scale, gallery, gallery_scale, B, N, D, k, index_base, vals, idx, ws, norm_bound, status,
+                        uncertified, score_events)
+    else:
+        st = _lib.lib().vpr_knn_topk_fp8_checked(_ptr(q), _ptr(q_scale), _ptr(gallery), _ptr(gallery_scale), B, N, D, int(k),
+                                                 int(index_base), _ptr(vals), _ptr(idx), _ptr(ws), ws.numel(),
+                                                 float(norm_bound), _ptr(status), _ptr(uncertified), _stream())
+        _lib.check(st, "vpr_knn_topk_fp8_checked")
     if exact_fallback:
         _exhaustive_fixup(q, q_scale, gallery, gallery_scale, k, index_base, status, vals, idx)
     return vals, idx

@@ -12,9 +12,8 @@ from typing import Optional
 
 import torch
 
-from . import ops
 from .modules import DinoV2Salad, FusedGeoPoseHead
-from .retrieval import ShardedGallery, all_gather_topk
+from .retrieval import ShardedGallery
 
 
 @dataclass
@@ -26,8 +25,6 @@ class StepOutput:
 
 
 class VPRGeoPosePipeline:
-    SPLIT_TIMING_MIN_ROWS = 4096       # below: the score stage may be K-split (vpr_knn_topk only): time the whole call
-
     def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10,
                  overlap_head: Optional[bool] = None):
         self.extractor, self.head, self.gallery, self.k = extractor, head, gallery, k
@@ -57,33 +54,8 @@ class VPRGeoPosePipeline:
                 pose = self.head(desc)
             desc.record_stream(side)
         q_all = g.gather_queries(desc16)
-        if self.knn_events is not None and getattr(g, "scales", None) is None and g.rows.shape[0] > self.SPLIT_TIMING_MIN_ROWS:
-            # same kernels as ShardedGallery.search, with HIP events around the score kernel
-            B = q_all.shape[0]
-            ws = ops.knn_workspace(B, g.rows.shape[0], q_all.shape[1], self.k, q_all.device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            ops.knn_scores(q_all, g.rows, ws)
-            e1.record()
-            self.knn_events.append((e0, e1))
-            v, i = ops.knn_select(q_all, g.rows, self.k, ws, g.index_base, norm_bound=g.norm_bound or ops.NORM_BOUND_BF16,
-                                  uncertified=g.uncertified)
-            if g.collective:
-                vs, is_ = all_gather_topk(v, i, g.world, g.group)
-                v, i = ops.topk_merge(vs, is_)
-        elif self.knn_events is not None:
-            # fp8 shard, or a shard small enough for the K-split form of the score stage (which only the whole
-            # vpr_knn_topk call runs): events around the whole local search
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            v, i = g._local(q_all, self.k)
-            e1.record()
-            self.knn_events.append((e0, e1))
-            if g.collective:
-                vs, is_ = all_gather_topk(v, i, g.world, g.group)
-                v, i = ops.topk_merge(vs, is_)
-        else:
-            v, i = g.search(q_all, self.k)
+        # knn_events: same kernels, run as the two stages of the call with HIP events around the score stage
+        v, i = g.search(q_all, self.k, score_events=self.knn_events)
         b = desc.shape[0]
         if g.collective:
             v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]

@@ -27,19 +27,21 @@ def shard_bounds(N: int, rank: int, world: int) -> Tuple[int, int]:
 class HipEngine:
     """Local top-k and merge on the gfx950 kernels."""
 
-    def local_topk(self, q, gallery, k, index_base, scales=None, norm_bound=None, uncertified=None, ws=None):
+    def local_topk(self, q, gallery, k, index_base, scales=None, norm_bound=None, uncertified=None, ws=None,
+                   score_events=None):
         """bf16 shard: q bf16.  fp8 shard (uint8 rows + per-row f32 `scales`): the gathered queries are
         quantised per row here (e4m3 + scale, vpr_quantize_fp8_rows) and searched by vpr_knn_topk_fp8.
         `uncertified` (int32 [1] on the device) counts queries whose answer the kernels could not certify as the
-        exact top-k (include/vpr_amd.h "Checked forms"); no host sync."""
+        exact top-k (include/vpr_amd.h "Checked forms"); no host sync.  score_events: see ops.knn_topk."""
         if gallery.dtype == torch.uint8:
             if scales is None:
                 raise ValueError("fp8 shard needs per-row scales")
             q8, qs = ops.quantize_fp8_rows(q.float())
             return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base, ws,
-                                    norm_bound=norm_bound or ops.NORM_BOUND_FP8, uncertified=uncertified)
+                                    norm_bound=norm_bound or ops.NORM_BOUND_FP8, uncertified=uncertified,
+                                    score_events=score_events)
         return ops.knn_topk(q, gallery, k, index_base, ws, norm_bound=norm_bound or ops.NORM_BOUND_BF16,
-                            uncertified=uncertified)
+                            uncertified=uncertified, score_events=score_events)
 
     def merge(self, vals, idxs):
         return ops.topk_merge(vals, idxs)
@@ -100,17 +102,18 @@ class ShardedGallery:
         dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
         return out
 
-    def _local(self, q_all: torch.Tensor, k: int, ws=None):
+    def _local(self, q_all: torch.Tensor, k: int, ws=None, score_events=None):
         if isinstance(self.engine, HipEngine):
             return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales, self.norm_bound,
-                                          self.uncertified, ws)
+                                          self.uncertified, ws, score_events)
         if self.scales is not None:
             return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales)
         return self.engine.local_topk(q_all, self.rows, k, self.index_base)
 
-    def search(self, q_all: torch.Tensor, k: int, ws=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """q_all [B, D]: the same on every rank.  Returns merged (vals [B,k], idx [B,k]) on every rank."""
-        v, i = self._local(q_all, k, ws)
+    def search(self, q_all: torch.Tensor, k: int, ws=None, score_events=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """q_all [B, D]: the same on every rank.  Returns merged (vals [B,k], idx [B,k]) on every rank.
+        score_events (HipEngine only): list collecting (start, end) timing events around the local score stage."""
+        v, i = self._local(q_all, k, ws, score_events)
         if not self.collective:
             return v, i
         vs, is_ = all_gather_topk(v, i, self.world, self.group)
