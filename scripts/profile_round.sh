@@ -1,20 +1,23 @@
 #!/bin/bash
-# Round profile on the GPU box (run through gpurun): kernel trace + stats of the default bench run, and the two PMC
-# passes (FETCH_SIZE / WRITE_SIZE, separate: TCC slot budget) on the kNN kernels -> gpurun_out/; the summaries that get
-# committed under profiles/ are copied from there (scripts/pmc_summary.py writes the PMC one).
+# Round profile on the GPU box (run through gpurun): the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate: TCC slot
+# budget) on the kNN kernels, then kernel trace + stats of the default bench run -> gpurun_out/; the summaries that get
+# committed under profiles/ are copied from there by scripts/refresh_profiles.sh (scripts/pmc_summary.py writes the PMC one).
 #   usage: bash scripts/profile_round.sh r02
 set -e
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1
-echo "bench trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 $R/scripts/kernel_bench.py --only knn --iters 5 > $O/${TAG}_pmc_fetch.log 2>&1
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 $R/scripts/kernel_bench.py --only knn --iters 5 > $O/${TAG}_pmc_write.log 2>&1
 echo "pmc write done"
 python3 $R/scripts/pmc_summary.py --fetch $O/${TAG}_pmc_fetch --write $O/${TAG}_pmc_write --out $O/${TAG}_knn_pmc.json
+# the bench run below quotes `roofline.traffic` from profiles/r02_knn_pmc.json when that summary was measured on the
+# kernel source it is about to run: put the fresh summary in place first
+cp $O/${TAG}_knn_pmc.json $R/profiles/r02_knn_pmc.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1
+echo "bench trace done"
 # matrix-pipe utilisation of the MFMA kernels (SALAD GEMMs, Sinkhorn aggregation, kNN score kernel)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $O/${TAG}_pmc_mfma -- python3 $R/scripts/kernel_bench.py --only knn,salad --iters 5 > $O/${TAG}_pmc_mfma.log 2>&1
 echo "pmc mfma done"

@@ -40,8 +40,8 @@ def test_bench_single_rank_contract(dev):
     c1 = c["config1_swin_tiny"]                               # BASELINE config 1: the reference's CPU-runnable case
     assert c1["cpu_images_per_s"] > 0 and c1["gpu_images_per_s"] > c1["cpu_images_per_s"]
     assert d["recall_at_1"] == 1.0 and "workload" in d["config"]
-    # 3000-row shard: the K-split form of the score stage, timed as the whole vpr_knn_topk call; no PMC traffic for it
-    assert "vpr::knn_scores_kernel<false, 208, 2, 4>" in r["kernel"] and "whole call" in r["kernel"] and r["traffic"] is None
+    # 3000-row shard: the K-split form of the score stage, timed between the two stages of the call; no PMC traffic for it
+    assert r["kernel"] == "vpr::knn_scores_kernel<false, 208, 2, 4>" and r["traffic"] is None and r["kernel_ms"] > 0
     assert d["uncertified_queries"] == 0
     rows = d["kernels"]                                       # per-kernel roofline rows (configs 2, 4, 5)
     assert {"salad_aggregate", "pose_head", "ln_meanpool_head_T49", "ln_meanpool_head_T144", "knn_topk_bf16",
