@@ -41,6 +41,39 @@ def test_knn_matches_oracle(dev, B, N, D, k):
     _check(dev, B, N, D, k)
 
 
+def _random_shapes(seed, count, fp8):
+    """Seeded shape sweep over every score route (stream / K-split stream / 128- and 256-tile GEMM, split-K or not),
+    ragged everything; sized so the CPU oracle (f64 brute force) stays within ~1 s per case."""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    step = 128 if fp8 else 64
+    for _ in range(count):
+        B = rnd.choice([rnd.randint(1, 64), rnd.randint(65, 191), rnd.randint(192, 256), rnd.randint(385, 600)])
+        D = rnd.choice([step * rnd.randint(1, 2048 // step)] * 3 + [8448, 4096])
+        N = rnd.choice([rnd.randint(1, 300), rnd.randint(301, 5000), rnd.randint(5001, 20000)])
+        N = max(1, min(N, int(6e9 / (B * D * 8))))            # bound the oracle's B x N x D f64 work
+        k = rnd.choice([1, 5, 10, rnd.randint(1, 64)])
+        out.append((B, N, D, k, rnd.randint(0, 10**6), rnd.choice([0, 0, 12345])))
+    return out
+
+
+@pytest.mark.parametrize("B,N,D,k,seed,base", _random_shapes(2026, 40, False))
+def test_knn_random_shapes_match_oracle(dev, B, N, D, k, seed, base):
+    _check(dev, B, N, D, k, seed=seed, index_base=base)
+
+
+@pytest.mark.parametrize("B,N,D,k,seed,base", _random_shapes(905, 28, True))
+def test_knn_fp8_random_shapes_match_oracle(dev, B, N, D, k, seed, base):
+    from vpr_amd import ops
+    q, qs = _fp8_rows(B, D, seed)
+    g, gs = _fp8_rows(N, D, seed + 1)
+    v_ref, i_ref = oknn.knn_topk_fp8(q, qs, g, gs, k, base)
+    v, i = ops.knn_topk_fp8(q.to(dev), qs.to(dev), g.to(dev), gs.to(dev), k, base)
+    assert torch.equal(i.cpu(), i_ref), f"indices differ B={B} N={N} D={D} k={k}"
+    assert torch.equal(v.cpu(), v_ref), f"values differ B={B} N={N} D={D} k={k}"
+
+
 def test_knn_fewer_rows_than_k(dev):
     from vpr_amd import ops
     q, g = _unit_rows(4, 64, 3), _unit_rows(3, 64, 4)

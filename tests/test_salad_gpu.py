@@ -94,7 +94,8 @@ def test_norm_shares_and_invariances(dev):
     assert (out_s - out).abs().max().item() < 1e-6
 
 
-@pytest.mark.parametrize("C,B", [(768, 3), (1024, 4), (1024, 64)])
+@pytest.mark.parametrize("C,B", [(768, 3), (1024, 4), (1024, 64),
+                                 (384, 1), (1536, 5), (1024, 33), (768, 17), (64, 2)])   # ViT-S / ViT-g widths, ragged batches
 def test_salad_end_to_end_matches_oracle(dev, C, B):
     """(1024, 64) is BASELINE config 2's shape — the only one that launches the full wave of 256 gemm256
     tiles (4x8 raster per XCD) and 64 Sinkhorn workgroups; the fp64 oracle costs ~40 GFLOP on the host."""
