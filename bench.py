@@ -200,8 +200,12 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
         unc = torch.zeros(1, dtype=torch.int32, device=dev)
         ms = _avg_ms(lambda: ops.knn_topk_fp8(q8, qs, g8, gs, a.k, 0, ws, uncertified=unc), n=5)
         by = N8 * D_DESC + N8 * 4 + B * D_DESC + B * a.k * 8
+        ev = []
+        _avg_ms(lambda: ops.knn_topk_fp8(q8, qs, g8, gs, a.k, 0, ws, score_events=ev), n=5)       # the same call as its two stages
+        ms_k = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
         rows["knn_topk_fp8"] = dict(entry="vpr_knn_topk_fp8_checked", shape=f"B={B} N={N8} D={D_DESC} e4m3 + per-row scale, k={a.k}",
-                                    uncertified_queries=int(unc), **hbm(by, ms))
+                                    uncertified_queries=int(unc), score_kernel=_lib.lib().vpr_knn_scores_kernel_name(1, B, N8).decode(),
+                                    score_kernel_ms=ms_k, score_kernel_frac=by / ms_k / 1e6 / HBM_PEAK_GBPS, **hbm(by, ms))
         gr = GraphedRetrieval(ShardedGallery(g8, N8, scales=gs), B, a.k)
         qb = torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
         ms_g = _avg_ms(lambda: gr(qb), n=5)

@@ -138,9 +138,12 @@ int vpr_knn_scores(const uint16_t* q, const uint16_t* gallery, int B, int N, int
 int vpr_knn_select(const uint16_t* q, const uint16_t* gallery, int B, int N, int D, int k,
                    int index_base, float* out_val, int32_t* out_idx,
                    void* workspace, size_t workspace_bytes, void* stream);
-/* Name (as a kernel trace shows it, without the argument list) of the kernel vpr_knn_scores / vpr_knn_topk[_fp8]
- * launches for the score stage of a B-query batch against an N-row shard: lets bench.py tie its roofline line to
- * profiles/ by name. */
+/* Name (as a kernel trace shows it, without the argument list) of the kernel vpr_knn_topk[_fp8] launches for the
+ * score stage of a B-query batch against an N-row shard of 8448-d descriptors: lets bench.py tie its roofline line to
+ * profiles/ by name.  <= 64 queries: knn_scores_kernel<fp8, tile rows, 2, flags> (208-row tiles, K split over up to
+ * 16 slabs below 106k rows; 256-row tiles above; above 131k rows — several tiles per workgroup — flags 52: score
+ * tiles leave as whole row segments through LDS with nt stores); more queries: gemm_nt / gemm256 (split-K for small
+ * shards). */
 const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N);
 /* Device pointer + leading dimension of the score matrix inside a workspace (for tests). */
 float* vpr_knn_scores_ptr(void* workspace, int B, int N, int D, int k, int* ld_out);

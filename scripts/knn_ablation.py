@@ -1,0 +1,52 @@
+"""Score-kernel ablations on the timing-only library (make -C .../csrc ablation; WRONG scores by construction):
+what the score stores cost inside the kernel = the in-kernel upper bound of fusing level-0 candidate extraction into
+the epilogue (VERDICT r1 #6b).  Events around the score stage of the real call (vpr_knn_topk_scores_stage).
+  VPR_AMD_LIBRARY=$PWD/visual-place-recognition-and-geopose-estimation_amd/libvpr_amd_ablation.so python scripts/knn_ablation.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vpr_amd import ops
+dev = torch.device("cuda:0")
+D, k, B = 8448, 10, 64
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def score_us(call, n=8):
+    ev = []
+    for _ in range(3):
+        call(ev)
+    ev.clear()
+    for _ in range(n):
+        call(ev)
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+    return ts[len(ts) // 2]
+
+
+for (N, fp8) in [(100_000, False), (500_000, False), (125_000, True), (1_000_000, True)]:
+    if fp8:
+        G = torch.empty((N, D), dtype=torch.uint8, device=dev)
+        gs = torch.empty((N,), dtype=torch.float32, device=dev)
+        for lo in range(0, N, 50000):
+            n = min(50000, N - lo)
+            G[lo:lo + n], gs[lo:lo + n] = ops.quantize_fp8_rows(torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=g), dim=1))
+        Q, qs = ops.quantize_fp8_rows(torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1))
+    else:
+        G = torch.empty((N, D), dtype=torch.bfloat16, device=dev)
+        for lo in range(0, N, 50000):
+            n = min(50000, N - lo)
+            G[lo:lo + n] = torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=g), dim=1).to(torch.bfloat16)
+        Q = torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1).to(torch.bfloat16)
+    ws = ops.knn_workspace(B, N, D, k, dev)
+    ws.zero_()
+    call = (lambda ev: ops.knn_topk_fp8(Q, qs, G, gs, k, 0, ws, score_events=ev)) if fp8 else \
+           (lambda ev: ops.knn_topk(Q, G, k, 0, ws, score_events=ev))
+    line = f"N={N:8d} {'e4m3' if fp8 else 'bf16'}:"
+    gb = N * D * (1 if fp8 else 2) / 1e3
+    for rep in range(2):
+        for variant, name in ((0, "shipped"), (14, "no score stores")):
+            os.environ["VPR_KNN_VARIANT"] = str(variant)
+            t = score_us(call)
+            line += f"  {name} {t:7.1f} us ({gb / t / 1e3:.2f} TB/s)"
+    os.environ["VPR_KNN_VARIANT"] = "0"
+    print(line, flush=True)
+    del G, ws

@@ -342,6 +342,7 @@ def _full_size_check(dev, B, N, k, fp8, seed, slab=65536, extra=16):
     (512, 125_000, 10, False),    # a 1M-row bf16 gallery on 8 GPUs: enough 256 x 256 tiles -> gemm256_kernel<false>, f32 out
     (64, 1_000_000, 10, True),    # config 5 unsharded: 1M x 8448 e4m3 (8.4 GB) on one GPU: 8 tiles of 245 rows per workgroup
     (16, 2_000_000, 10, True),    # 2M rows (16.9 GB): > 4096 level-0 candidates per query -> register select level + fused final
+    (64, 500_000, 10, False),     # 8.4 GB of bf16 rows: 4 tiles of 245 rows per workgroup, staged score stores
 ])
 def test_knn_full_size_exact(dev, B, N, k, fp8):
     _full_size_check(dev, B, N, k, fp8, seed=B + N)
@@ -506,3 +507,33 @@ def test_knn_default_bound_certifies_normalised_descriptors(dev):
     unc = torch.zeros(1, dtype=torch.int32, device=dev)
     ops.knn_topk(q, g, k, status=status, uncertified=unc)
     assert int(status.max()) == 0 and int(unc) == 0
+
+
+
+# ----------------------------------------------------------------- score-store paths
+@pytest.mark.parametrize("B,N,D,fp8", [(64, 20000, 8448, False), (64, 20000, 8448, True), (7, 1003, 256, False),
+                                       (64, 131, 128, True), (33, 5, 64, False), (50, 150_001, 128, False)])
+@pytest.mark.parametrize("variant", ["6", "7"])
+def test_knn_staged_score_stores_equal_direct(dev, monkeypatch, B, N, D, fp8, variant):
+    """The score kernel of multi-tile shards (N > 131k rows) writes each tile's scores as whole row segments staged
+    through LDS (VPR_KNN_VARIANT 6 / 7 force that path, plain / nt stores, at any size): the score matrix and the answer
+    are bit-identical to the direct-store kernel's (variant 5), ragged tiles, batches and row counts included."""
+    from vpr_amd import ops
+    k = 5
+    if fp8:
+        q, qs = _fp8_rows(B, D, 91)
+        g, gs = _fp8_rows(N, D, 92)
+        args = (q.to(dev), qs.to(dev), g.to(dev), gs.to(dev), k, 0)
+        fn = ops.knn_topk_fp8
+    else:
+        args = (_unit_rows(B, D, 91).to(dev), _unit_rows(N, D, 92).to(dev), k, 0)
+        fn = ops.knn_topk
+    monkeypatch.setenv("VPR_KNN_GEMM_MIN_B", "100000")
+    outs = []
+    for var in ("5", variant):
+        monkeypatch.setenv("VPR_KNN_VARIANT", var)
+        ws = ops.knn_workspace(B, N, D, k, dev)
+        ws.zero_()
+        v, i = fn(*args, ws)
+        outs.append((ops.knn_scores_view(ws, B, N, D, k).clone(), v, i))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

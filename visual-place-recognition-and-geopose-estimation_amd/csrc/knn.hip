@@ -62,12 +62,14 @@ __global__ __launch_bounds__(256, WGPC) void knn_scores_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwg = gridDim.x;
   const int qb = blockIdx.y;
-  const long long r_begin = (long long)N * blockIdx.x / nwg;
-  const long long r_end = (long long)N * (blockIdx.x + 1) / nwg;
+  // balanced static partition in units of 4 rows (16-byte aligned score-row segments for the epilogue's float4 stores)
+  const long long n4 = ((long long)N + 3) >> 2;
+  const long long r_begin = 4 * (n4 * blockIdx.x / nwg);
+  const long long r_end = min((long long)N, 4 * (n4 * (blockIdx.x + 1) / nwg));
   const int len = (int)(r_end - r_begin);
   if (len <= 0) return;
   const int ntile = (len + KNN_TR - 1) / KNN_TR;
-  const int th_nom = (len + ntile - 1) / ntile;
+  const int th_nom = ((len + ntile - 1) / ntile + 3) & ~3;      // <= KNN_TR (a multiple of 16)
   // K slice of this workgroup (small shards: gridDim.z > 1 slices, each into its own score slab, summed by the
   // level-0 select in slice order — see knn_ksplit)
   const int nk_all = row_bytes >> 7;
@@ -158,16 +160,60 @@ __global__ __launch_bounds__(256, WGPC) void knn_scores_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) qs[e] = q_scale[min(qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e, B - 1)];
     }
+    if constexpr (ABL & 32) {
+      // Score tile out through the (now idle) stage buffers as whole row segments: wave w owns query rows 16w..16w+15
+      // of the tile on both sides, so only the first barrier (every wave is past its last operand read) is needed.
+      // Pitch KNN_TR + 4 floats: the four query groups of a store land 16 banks apart (conflict-free), rows stay
+      // 16-byte aligned.  One 1-KiB float4 store per query row instead of 16 dword stores of four 64-byte segments.
+      constexpr int SP = KNN_TR + 4;
+      static_assert(KNN_QT * SP * 4 <= 2 * STAGE_BYTES, "score tile must fit the stage buffers");
+      float* st = reinterpret_cast<float*>(smem);
+      __syncthreads();
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = 16 * nb + (lane & 15);
-      if (n < th) {
-        float gs = 1.f;
-        if constexpr (FP8) gs = g_scale[row0 + n];
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + (lane & 15);
+        if (n < th) {
+          float gs = 1.f;
+          if constexpr (FP8) gs = g_scale[row0 + n];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e;
-          if (q < B) S[(long long)q * ldS + row0 + n] = FP8 ? acc[nb][e] * qs[e] * gs : acc[nb][e];
+          for (int e = 0; e < 4; ++e)
+            st[(16 * wave + 4 * (lane >> 4) + e) * SP + n] = FP8 ? acc[nb][e] * qs[e] * gs : acc[nb][e];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int j = 0; j < 16; ++j) {
+        const int q = qb * KNN_QT + 16 * wave + j;
+        if (q >= B) break;
+        float* dst = S + (long long)q * ldS + row0;
+        const float* srow = st + (16 * wave + j) * SP;
+        for (int c = lane * 4; c < th; c += 256) {
+          if (c + 3 < th) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(srow + c);
+            if constexpr (ABL & 16) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst + c));
+            else *reinterpret_cast<f32x4*>(dst + c) = v4;
+          } else {
+            for (int x = c; x < th; ++x) dst[x] = srow[x];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = 16 * nb + (lane & 15);
+        if (n < th) {
+          float gs = 1.f;
+          if constexpr (FP8) gs = g_scale[row0 + n];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = qb * KNN_QT + 16 * wave + 4 * (lane >> 4) + e;
+            // ABL bit 3 (value 8, -DVPR_ABLATION builds only): no score stores (the impossible compare keeps the MFMAs alive)
+            if ((ABL & 8) && acc[nb][e] != 12345.678f) continue;
+            const float val = FP8 ? acc[nb][e] * qs[e] * gs : acc[nb][e];
+            if (q < B) {
+              if constexpr (ABL & 16) __builtin_nontemporal_store(val, &S[(long long)q * ldS + row0 + n]);
+              else S[(long long)q * ldS + row0 + n] = val;
+            }
+          }
         }
       }
     }
@@ -964,6 +1010,12 @@ static bool knn_tall_tiles(int N) {
   return (N + slots - 1) / slots > 208;
 }
 
+// more than one 256-row tile per workgroup of the resident grid (N > 131k rows)
+static bool knn_multi_tile(int N) {
+  const int slots = num_cus() * 2;
+  return (N + slots - 1) / slots > 256;
+}
+
 // 256-row query tiles pay when at least 3/4 of their rows are real queries (256 gathered queries = 4 GPUs, 512 = 8 GPUs);
 // VPR_KNN_FP8_GEMM256=0 forces the 128 x 128 kernel (A/B).
 static bool knn_fp8_use_gemm256(int B) {
@@ -1049,7 +1101,15 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // Shards whose workgroups own more than one 208-row tile (N > 106k) take 256-row tiles: 16 row blocks, 2 x 80 KB = the
   // whole 160 KB of LDS, fewer tiles and 20 % less query re-staging: +2.3 % at 500k bf16 rows, +1.4 % on the 1M-row e4m3
   // call; a 125k-row shard becomes one 244-row tile per workgroup instead of two of 122 (scripts/knn_ab.py, knn_ab_fp8.py).
-  if (variant == 3 || (variant == 0 && knn_tall_tiles(N))) { tr = 256; wgpc = 2; }
+  if (variant == 3 || ((variant == 0 || (variant >= 5 && variant <= 7) || variant == 14) && knn_tall_tiles(N))) { tr = 256; wgpc = 2; }
+  // Score-store path.  Shards whose workgroups own several tiles (N > 131k) write each tile's scores as whole row
+  // segments staged through the idle stage buffers (one 1-KiB float4 store per query row, nt policy) instead of dword
+  // stores of four 64-byte segments: the stores of a large shard cost far more than their 1.5-3 % share of the bytes
+  // (no-store ablation, score stage: 1M e4m3 rows 1518 -> 1245 us, 500k bf16 1391 -> 1252, 125k e4m3 170 -> 159,
+  // 100k bf16 ~0).  Staged + nt: 1M e4m3 1497 -> 1342 us, 500k bf16 1374 -> 1300, 250k bf16 668 -> 642; single-tile
+  // shards: no difference, they keep the direct stores.  Variants 5 / 6 / 7 force direct / staged / staged + nt.
+  const bool staged = variant == 6 || variant == 7 || (variant == 0 && knn_multi_tile(N));
+  const bool staged_nt = variant != 6;
   const int slots = num_cus() * wgpc;
   // Fully resident, balanced grid; never more workgroups than 16-row blocks of gallery.
   int nwg = slots;
@@ -1074,6 +1134,23 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   } while (0)
   // ABL bit 2 (value 4) = nt cache policy on the gallery stream (read once; keeps the query tile and the score
   // matrix in L2 / Infinity Cache): +4.6 % on the bare stream, +5.2 % on this kernel at 100k rows.
+  if (staged) {                                   // 4 | 32 (| 16)
+#define VPR_KNN_STAGED(F8)                                                                           \
+    do {                                                                                               \
+      if (tr == 256) { if (staged_nt) VPR_KNN_LAUNCH(F8, 256, 2, 52); else VPR_KNN_LAUNCH(F8, 256, 2, 36); } \
+      else { if (staged_nt) VPR_KNN_LAUNCH(F8, 208, 2, 52); else VPR_KNN_LAUNCH(F8, 208, 2, 36); }          \
+    } while (0)
+    if (o.fp8) VPR_KNN_STAGED(true); else VPR_KNN_STAGED(false);
+#undef VPR_KNN_STAGED
+    return VPR_OK;
+  }
+#ifdef VPR_ABLATION
+  if (variant == 14) {                            // timing only: no score stores
+    if (o.fp8) { if (tr == 256) VPR_KNN_LAUNCH(true, 256, 2, 12); else VPR_KNN_LAUNCH(true, 208, 2, 12); }
+    else { if (tr == 256) VPR_KNN_LAUNCH(false, 256, 2, 12); else VPR_KNN_LAUNCH(false, 208, 2, 12); }
+    return VPR_OK;
+  }
+#endif
   if (o.fp8) {
     if (variant == 2) VPR_KNN_LAUNCH(true, 144, 3, 4);
     else if (tr == 256) VPR_KNN_LAUNCH(true, 256, 2, 4);
@@ -1226,6 +1303,8 @@ extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N) {
   const char* venv = getenv("VPR_KNN_VARIANT");
   const int variant = venv ? atoi(venv) : 0;
   const bool tall = variant == 3 || (variant == 0 && knn_tall_tiles(N));
+  if (variant == 0 && knn_multi_tile(N))
+    return is_fp8 ? "vpr::knn_scores_kernel<true, 256, 2, 52>" : "vpr::knn_scores_kernel<false, 256, 2, 52>";
   if (is_fp8) {
     return variant == 2 ? "vpr::knn_scores_kernel<true, 144, 3, 4>" : tall ? "vpr::knn_scores_kernel<true, 256, 2, 4>"
          : variant == 1 ? "vpr::knn_scores_kernel<true, 208, 2, 0>" : "vpr::knn_scores_kernel<true, 208, 2, 4>";
