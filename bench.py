@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="with one rank: still create the process group (RCCL) and run the two all-gathers + merge of the "
                          "sharded path (launch under torch.distributed.run --nproc-per-node 1, or bare: 127.0.0.1 rendezvous)")
+    ap.add_argument("--graph-retrieval", action="store_true",
+                    help="retrieval leg of every step = one HIP-graph replay of {query all-gather, shard search, top-k all-gather, "
+                         "merge} (BASELINE config 5: --knn-dtype fp8 --gallery 1000000 --graph-retrieval on 8 GPUs)")
     ap.add_argument("--no-kernel-rows", action="store_true", help="skip the per-kernel roofline rows measured after the timed region")
     ap.add_argument("--fp8-rows", type=int, default=1_000_000, help="gallery rows of the e4m3 kNN row (BASELINE config 5 on one GPU)")
     a = ap.parse_args()
@@ -347,7 +350,7 @@ def main():
         gallery = ShardedGallery(g8, a.gallery, rank, world, scales=gs, force_collectives=a.force_dist)
     else:
         gallery = ShardedGallery(shard, a.gallery, rank, world, force_collectives=a.force_dist)
-    pipe = VPRGeoPosePipeline(ext, head, gallery, a.k)
+    pipe = VPRGeoPosePipeline(ext, head, gallery, a.k, graph_retrieval=a.graph_retrieval)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     images = torch.randn(a.batch, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
 
@@ -412,7 +415,14 @@ def main():
             traffic, traffic_source = None, None
 
     # knn_avg_s = the score stage alone (HIP events between the two stages of vpr_knn_topk*, same kernels as the one-call form)
-    if bq <= 64:
+    if a.graph_retrieval:
+        # a graph has no seam for events: the whole replay (collectives, quantisation, scores, select, merge) is the timed unit
+        roofline = {"bound": "hbm", "kernel": f"hipGraph replay of the retrieval leg ({'2 all-gathers + merge + ' if gallery.collective else ''}"
+                                              f"{'query quantisation + ' if a.knn_dtype == 'fp8' else ''}{score_kernel} + select)",
+                    "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                    "kernel_ms": knn_avg_s * 1e3, "algorithmic_bytes": alg_bytes}
+    elif bq <= 64:
         roofline = {"bound": "hbm", "kernel": score_kernel,
                     "achieved": alg_bytes / knn_avg_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": alg_bytes / knn_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
@@ -464,7 +474,8 @@ def main():
                                    f"{a.gallery}-row x {D_DESC} synthetic gallery sharded {world} way(s) + fused "
                                    f"(lat,lon,sin,cos) head; 3x224x224 bf16 images",
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "gallery_rows": a.gallery,
-                       "k": a.k, "parallelism": f"dp{world}+gallery-shard{world}", "batches_in_flight": a.in_flight},
+                       "k": a.k, "parallelism": f"dp{world}+gallery-shard{world}", "batches_in_flight": a.in_flight,
+                       "graph_retrieval": bool(a.graph_retrieval)},
             "roofline": roofline,
             "recall_at_1": recall1,
             "uncertified_queries": gallery.uncertified_queries(),    # kNN answers the device could not certify exact (0 expected)

@@ -74,6 +74,25 @@ def test_bench_force_dist_runs_the_collectives_on_rccl(dev):
     assert d["config"]["batches_in_flight"] == 2 and d["dist"]["collectives_in_step"] and d["recall_at_1"] == 1.0
 
 
+def test_bench_config5_flags_graph_retrieval_with_collectives(dev):
+    """BASELINE config 5 as the driver (or anyone with an 8-GPU node) would launch it, on the one rank available here:
+    e4m3 gallery, the retrieval leg of every step replayed from ONE HIP graph that holds both RCCL all-gathers, the
+    query quantisation, the shard search and the merge."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--knn-dtype", "fp8",
+                        "--graph-retrieval", "--no-cpu-baseline", "--no-kernel-rows"] + SMALL,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _json_line(p.stdout)
+    assert d["config"]["graph_retrieval"] is True and d["dist"]["collectives_in_step"] and "fp8" in d["dtype"]
+    assert "hipGraph replay" in d["roofline"]["kernel"] and "all-gathers" in d["roofline"]["kernel"] and d["roofline"]["kernel_ms"] > 0
+    assert d["value"] > 0 and d["recall_at_1"] == 1.0 and d["uncertified_queries"] == 0
+
+
 def test_bench_fp8_gallery(dev):
     """--knn-dtype fp8: e4m3 shard + per-row scales through the same pipeline; planted neighbours still found."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--knn-dtype", "fp8",

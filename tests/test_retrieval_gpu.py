@@ -122,3 +122,39 @@ def test_pipeline_head_on_side_stream_equals_in_stream(rccl_one_rank):
     for o in outs[1:]:
         assert torch.equal(o.pose, outs[0].pose) and torch.equal(o.topk_indices, outs[0].topk_indices)
         assert torch.equal(o.topk_scores, outs[0].topk_scores) and torch.equal(o.descriptors, outs[0].descriptors)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_pipeline_graph_retrieval_equals_eager(rccl_one_rank, fp8):
+    """VPRGeoPosePipeline(graph_retrieval=True): the retrieval leg of a step is one HIP-graph replay (captured at the
+    first step, collectives inside) — bit-identical StepOutput to the eager pipeline, step after step."""
+    import torch.nn as nn
+    from vpr_amd import ops
+    from vpr_amd.modules import DinoV2Salad, FusedGeoPoseHead
+    from vpr_amd.pipeline import VPRGeoPosePipeline
+    from vpr_amd.retrieval import ShardedGallery
+    dev = rccl_one_rank
+    torch.manual_seed(1)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    pos = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    ang = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    head = FusedGeoPoseHead(pos, ang, normalize=True)
+    gal = torch.nn.functional.normalize(torch.randn(7000, 8448, device=dev), dim=1)
+    if fp8:
+        g8, gs = ops.quantize_fp8_rows(gal)
+        make = lambda: ShardedGallery(g8, 7000, 0, 1, scales=gs, force_collectives=True)
+    else:
+        rows = gal.to(torch.bfloat16)
+        make = lambda: ShardedGallery(rows, 7000, 0, 1, force_collectives=True)
+    eager = VPRGeoPosePipeline(ext, head, make(), 5)
+    graphed = VPRGeoPosePipeline(ext, head, make(), 5, graph_retrieval=True)
+    graphed.knn_events = []
+    for trial in range(3):
+        images = torch.randn(4, 3, 224, 224, device=dev, generator=torch.Generator(device=dev).manual_seed(trial)).to(torch.bfloat16)
+        a, b = eager.step(images), graphed.step(images)
+        torch.cuda.synchronize()
+        assert torch.equal(a.topk_indices, b.topk_indices) and torch.equal(a.topk_scores, b.topk_scores), trial
+        assert torch.equal(a.pose, b.pose) and torch.equal(a.descriptors, b.descriptors)
+    assert len(graphed.knn_events) == 3 and len(graphed._graphed) == 1
+    assert graphed.gallery.uncertified_queries() == 0

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from .modules import DinoV2Salad, FusedGeoPoseHead
-from .retrieval import ShardedGallery
+from .retrieval import GraphedRetrieval, ShardedGallery
 
 
 @dataclass
@@ -26,9 +26,15 @@ class StepOutput:
 
 class VPRGeoPosePipeline:
     def __init__(self, extractor: DinoV2Salad, head: FusedGeoPoseHead, gallery: ShardedGallery, k: int = 10,
-                 overlap_head: Optional[bool] = None):
+                 overlap_head: Optional[bool] = None, graph_retrieval: bool = False):
+        """graph_retrieval: the retrieval leg of every step — {query all-gather, local shard search, packed top-k
+        all-gather, merge} — is ONE HIP-graph replay (retrieval.GraphedRetrieval, captured at the first step of a given
+        batch size; every rank must step in lockstep, as with the eager collectives).  BASELINE config 5's "hipGraph-
+        captured per-batch retrieval"."""
         self.extractor, self.head, self.gallery, self.k = extractor, head, gallery, k
-        self.knn_events = None     # optional list collecting (start, end) events of the score kernel
+        self.graph_retrieval = graph_retrieval
+        self._graphed = {}
+        self.knn_events = None     # optional list collecting (start, end) events of the score kernel (graph: of the replay)
         # The pose head needs only the descriptor; the retrieval leg (two collectives with launch-latency gaps between
         # them when the gallery is sharded) runs beside it: head on a side stream, joined at the end of the step.
         self.overlap_head = gallery.collective if overlap_head is None else overlap_head
@@ -53,12 +59,26 @@ class VPRGeoPosePipeline:
             with torch.cuda.stream(side):
                 pose = self.head(desc)
             desc.record_stream(side)
-        q_all = g.gather_queries(desc16)
-        # knn_events: same kernels, run as the two stages of the call with HIP events around the score stage
-        v, i = g.search(q_all, self.k, score_events=self.knn_events)
-        b = desc.shape[0]
-        if g.collective:
-            v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]
+        if self.graph_retrieval:
+            key = (desc16.shape[0], torch.cuda.current_stream(desc.device).cuda_stream)   # one graph (and its buffers) per lane
+            gr = self._graphed.get(key)
+            if gr is None:
+                gr = self._graphed[key] = GraphedRetrieval(g, desc16.shape[0], self.k)
+            if self.knn_events is not None:                # a graph has no seam for events: the whole replay is timed
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            v, i = gr(desc16)
+            if self.knn_events is not None:
+                e1.record()
+                self.knn_events.append((e0, e1))
+            v, i = v.clone(), i.clone()                    # the graph's output buffers are rewritten by the next replay
+        else:
+            q_all = g.gather_queries(desc16)
+            # knn_events: same kernels, run as the two stages of the call with HIP events around the score stage
+            v, i = g.search(q_all, self.k, score_events=self.knn_events)
+            if g.collective:
+                b = desc.shape[0]
+                v, i = v[g.rank * b:(g.rank + 1) * b], i[g.rank * b:(g.rank + 1) * b]
         if self.overlap_head:
             main.wait_stream(side)
             pose.record_stream(main)

@@ -148,9 +148,12 @@ class GraphedRetrieval:
         self.ws = ops.knn_workspace(B, rows.shape[0], D, k, dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        counted = gallery.uncertified.clone() if gallery.uncertified is not None else None
         with torch.cuda.stream(side):            # warm-up outside capture: module load, allocator, communicator set-up
             for _ in range(2):
                 self._run()
+            if counted is not None:              # the warm-up's all-zero queries (every score ties) are not searches
+                gallery.uncertified.copy_(counted)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
