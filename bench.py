@@ -121,6 +121,22 @@ def _avg_ms(fn, n=10, warm=2):
     return e0.elapsed_time(e1) / n
 
 
+def pmc_traffic(summary: str, kernel: str):
+    """HBM bytes per launch of `kernel` from a committed PMC summary (scripts/pmc_summary.py), only if that summary was
+    measured on the kernel source this run is about to launch (hash of knn.hip + vpr_common.h) -> (bytes, source) or (None, None)."""
+    path = os.path.join(ROOT, "profiles", summary)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from pmc_summary import kernel_source_sha16
+        with open(path) as f:
+            pj = json.load(f)
+        if pj.get("source_sha16") == kernel_source_sha16(ROOT) and kernel in pj.get("kernels", {}):
+            return pj["kernels"][kernel]["hbm_bytes_per_launch"], f"profiles/{summary} (source_sha16 {pj['source_sha16']}, {kernel})"
+    except Exception:                                           # noqa: BLE001  a missing / broken summary only costs the traffic figure
+        pass
+    return None, None
+
+
 def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
     """Roofline rows of the other hand-written stages (BASELINE configs 2, 4, 5), each timed on its own after the timed
     region: algorithmic FLOPs / bytes over the average device time of the whole entry point."""
@@ -206,6 +222,9 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
         rows["knn_topk_fp8"] = dict(entry="vpr_knn_topk_fp8_checked", shape=f"B={B} N={N8} D={D_DESC} e4m3 + per-row scale, k={a.k}",
                                     uncertified_queries=int(unc), score_kernel=_lib.lib().vpr_knn_scores_kernel_name(1, B, N8).decode(),
                                     score_kernel_ms=ms_k, score_kernel_frac=by / ms_k / 1e6 / HBM_PEAK_GBPS, **hbm(by, ms))
+        if B == 64 and N8 == 1_000_000:
+            t8, src8 = pmc_traffic("r02_knn8_pmc.json", rows["knn_topk_fp8"]["score_kernel"])
+            rows["knn_topk_fp8"].update(score_kernel_traffic=t8, traffic_source=src8)
         gr = GraphedRetrieval(ShardedGallery(g8, N8, scales=gs), B, a.k)
         qb = torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
         ms_g = _avg_ms(lambda: gr(qb), n=5)
@@ -401,18 +420,11 @@ def main():
     # quoted only if the summary was measured on THIS kernel source and names the kernel this run launched.
     traffic, traffic_source = None, None
     score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq, n_shard).decode()
-    pmc = os.path.join(ROOT, "profiles", "r02_knn_pmc.json")
-    if os.path.exists(pmc) and world == 1 and a.gallery == 100_000 and a.batch == 64 and a.knn_dtype == "bf16":
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "scripts"))
-            from pmc_summary import kernel_source_sha16
-            with open(pmc) as f:
-                pj = json.load(f)
-            if pj.get("source_sha16") == kernel_source_sha16(ROOT) and score_kernel in pj.get("kernels", {}):
-                traffic = pj["kernels"][score_kernel]["hbm_bytes_per_launch"]
-                traffic_source = f"profiles/r02_knn_pmc.json (source_sha16 {pj['source_sha16']}, {score_kernel})"
-        except Exception:                                       # noqa: BLE001  a broken summary only costs the traffic figure
-            traffic, traffic_source = None, None
+    if world == 1 and a.batch == 64 and not a.graph_retrieval:
+        if a.gallery == 100_000 and a.knn_dtype == "bf16":
+            traffic, traffic_source = pmc_traffic("r02_knn_pmc.json", score_kernel)
+        elif a.gallery == 1_000_000 and a.knn_dtype == "fp8":
+            traffic, traffic_source = pmc_traffic("r02_knn8_pmc.json", score_kernel)
 
     # knn_avg_s = the score stage alone (HIP events between the two stages of vpr_knn_topk*, same kernels as the one-call form)
     if a.graph_retrieval:
