@@ -311,6 +311,10 @@ def test_forced_collectives_single_rank_gloo_and_fp8_shard_helper(tmp_path):
         q8, qs = oknn.quantize_fp8_rows(q.float())
         v8r, i8r = oknn.knn_topk_fp8(q8, qs, g8, gs, k)
         assert torch.equal(i8, i8r) and torch.equal(v8, v8r)
+        # collectives are only capturable on RCCL: the graphed form refuses a gloo group instead of failing mid-capture
+        from vpr_amd.retrieval import GraphedRetrieval
+        with pytest.raises(RuntimeError, match="RCCL"):
+            GraphedRetrieval(sg, B, k)
     finally:
         dist.destroy_process_group()
 

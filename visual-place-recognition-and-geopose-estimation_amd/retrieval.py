@@ -141,6 +141,9 @@ class GraphedRetrieval:
 
     def __init__(self, gallery: ShardedGallery, batch_local: int, k: int):
         self.g, self.k, self.b = gallery, k, batch_local
+        if gallery.collective and dist.get_backend(gallery.group) != "nccl":
+            raise RuntimeError("GraphedRetrieval: collectives can only be captured on the RCCL ('nccl') backend; "
+                               f"this process group is '{dist.get_backend(gallery.group)}' — use the eager search")
         rows = gallery.rows
         dev, D = rows.device, rows.shape[1]
         self.q = torch.zeros((batch_local, D), dtype=torch.bfloat16, device=dev)
