@@ -1018,7 +1018,7 @@ static bool knn_multi_tile(int N) {
 
 // 256-row query tiles pay when at least 3/4 of their rows are real queries (256 gathered queries = 4 GPUs, 512 = 8 GPUs);
 // VPR_KNN_FP8_GEMM256=0 forces the 128 x 128 kernel (A/B).
-static bool knn_fp8_use_gemm256(int B) {
+static bool knn_query_tile256_pays(int B) {
   const char* e = getenv("VPR_KNN_FP8_GEMM256");
   if (e && !atoi(e)) return false;
   const int tiles = (B + 255) / 256;
@@ -1044,7 +1044,7 @@ static KnnRoute knn_route(const KnnPlan& p, bool fp8, int B, int N, int D, bool 
     if (ksplit_ok) *nslab = knn_ksplit(p, rb);
     return ROUTE_STREAM;
   }
-  if (!knn_fp8_use_gemm256(B) || (fp8 && D < 256)) return ROUTE_GEMM128;
+  if (!knn_query_tile256_pays(B) || (fp8 && D < 256)) return ROUTE_GEMM128;
   // 256 x 256 tiles, one workgroup per CU: with the K split a 512 x 12.5k problem (98 tiles) runs as 196 workgroups.
   // Without it (stand-alone score entry point, or VPR_KNN_GEMM_KSPLIT=0) bf16 needs >= 256 tiles to beat the 128 x 128
   // kernel's 4x as many workgroups.
