@@ -361,3 +361,29 @@ def test_retrieval_evaluation_entry_points(dev, tmp_path, fp8):
     assert res["maae"] == pytest.approx(5.0)
     assert res["recall_at_1_tau"] == 1.0 and res["recall_at_1_region"] == 1.0 and res["uncertified_queries"] == 0
     assert (res["topk_scores"][:, 0] > res["topk_scores"][:, 1]).all()
+
+
+def test_image_batch_loader_on_gpu_equals_serial_decode(dev, tmp_path):
+    """vpr_amd.loader.ImageBatchLoader on the GPU path (pinned ring, copy stream, event hand-off): the uint8 batches are
+    the serial PIL decode's bytes, in plan order, while the consumer keeps the device busy between batches."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from vpr_amd.loader import ImageBatchLoader
+    rng = np.random.default_rng(1)
+    names = []
+    for i in range(37):
+        W, H = ((96, 64), (50, 70))[(i // 5) % 2]
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(os.path.join(tmp_path, f"{i:03d}.png"))
+        names.append(f"{i:03d}.png")
+    ref = {f: np.asarray(Image.open(os.path.join(tmp_path, f)).convert("RGB")) for f in names}
+    busy = torch.randn(2048, 2048, device=dev)
+    seen = 0
+    for idxs, bnames, u8 in ImageBatchLoader(str(tmp_path), names, 8, dev, workers=6, depth=2):
+        assert u8.is_cuda and u8.dtype == torch.uint8
+        busy = busy @ busy * 1e-3                                   # work queued behind the copy's event on the consumer stream
+        host = u8.cpu().numpy()
+        for j, f in enumerate(bnames):
+            assert np.array_equal(host[j], ref[f]) and names[idxs[j]] == f
+        seen += len(idxs)
+    assert seen == len(names)

@@ -1,0 +1,55 @@
+"""Decode-ahead loader (vpr_amd/loader.py) on the CPU device: same bytes, batches and order as the serial PIL loop."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+
+def _write_images(tmp_path, n, sizes=((64, 48), (32, 32))):
+    rng = np.random.default_rng(0)
+    names = []
+    for i in range(n):
+        W, H = sizes[(i // 3) % len(sizes)]                       # runs of 3 per size: groups interleave in the file list
+        arr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        name = f"im_{i:03d}.{'png' if i % 2 else 'jpg'}"
+        Image.fromarray(arr).save(os.path.join(tmp_path, name), quality=90)
+        names.append(name)
+    return names
+
+
+def _serial(image_dir, names):
+    return {f: np.asarray(Image.open(os.path.join(image_dir, f)).convert("RGB")) for f in names}
+
+
+@pytest.mark.parametrize("workers,depth", [(1, 1), (4, 3), (8, 2)])
+def test_loader_equals_serial_decode(tmp_path, workers, depth):
+    from vpr_amd.loader import ImageBatchLoader, batches_by_size
+    names = _write_images(str(tmp_path), 23)
+    ref = _serial(str(tmp_path), names)
+    plan = batches_by_size(str(tmp_path), names, 4)
+    assert [s for s, _, _ in plan][:2] == [(64, 48)] * 2           # first size first, in order of first appearance
+    seen = []
+    ld = ImageBatchLoader(str(tmp_path), names, 4, "cpu", workers=workers, depth=depth)
+    assert len(ld) == len(plan)
+    for (size, idxs_p, names_p), (idxs, bnames, u8) in zip(plan, ld):
+        assert idxs == idxs_p and bnames == names_p
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (len(idxs), size[1], size[0], 3)
+        for j, f in enumerate(bnames):
+            assert np.array_equal(u8[j].numpy(), ref[f]), f
+            assert names[idxs[j]] == f
+        seen += idxs
+    assert sorted(seen) == list(range(len(names)))
+    # a second pass over the same loader object decodes again (fresh ring, same result)
+    assert sum(len(i) for i, _, _ in ld) == len(names)
+
+
+def test_loader_reports_a_broken_file(tmp_path):
+    from vpr_amd.loader import ImageBatchLoader
+    names = _write_images(str(tmp_path), 6, sizes=((16, 16),))
+    with open(os.path.join(tmp_path, names[4]), "r+b") as f:        # keep the header (size probe passes), cut the data
+        f.truncate(60)
+    with pytest.raises(Exception):
+        for _ in ImageBatchLoader(str(tmp_path), names, 2, "cpu", workers=2):
+            pass

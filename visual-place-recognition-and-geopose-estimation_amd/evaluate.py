@@ -6,8 +6,9 @@ the reference's validation scripts, running on the MI355X path.
   calculate_swin_validation_scores(checkpoint_path, val_csv_path, image_dir, preds_csv)
       swin_transformer/swin_validation.py:48-134     (Swin pooler + Linear head, ID-sorted preds.csv)
 
-What differs from the reference loop: images are decoded on the host (PIL) but
-resized / normalised on the GPU (vpr_amd.preprocess, PIL-exact), batches stay on the device until
+What differs from the reference loop: images are decoded on the host (PIL, by a thread
+pool running a few batches ahead into pinned buffers: vpr_amd.loader) but resized / normalised on the
+GPU (vpr_amd.preprocess, PIL-exact), batches stay on the device until
 the end (one D2H copy instead of one per batch), the model objects are passed in or built from a
 state dict instead of being fetched by name (torch.hub / from_pretrained need the network), and
 the scaler is a LatLonScaler (JSON or the campus constants) instead of a joblib pickle.
@@ -23,6 +24,7 @@ import torch
 from PIL import Image
 
 from . import postproc, reports
+from .loader import ImageBatchLoader
 from .modules import DINOv2RegressionModel, DinoV2Salad, load_reference_checkpoint
 from .preprocess import HALF_MEAN, HALF_STD, IMAGENET_MEAN, IMAGENET_STD, ResizeNormalize
 
@@ -35,23 +37,11 @@ def _existing_rows(val_csv_path: str, image_dir: str) -> pd.DataFrame:
     return filtered.reset_index(drop=True)
 
 
-def _load_batch(image_dir: str, filenames, device) -> torch.Tensor:
-    """Decode a batch to uint8 [B,H,W,3] on the device (all images of a batch must share one size;
-    mixed sizes are handled by the caller batching per size)."""
-    arrs = [np.asarray(Image.open(os.path.join(image_dir, f)).convert("RGB")) for f in filenames]
-    return torch.from_numpy(np.stack(arrs)).to(device)
-
-
-def _batches_by_size(image_dir: str, filenames, batch_size: int):
-    """Yield (indices, filenames) groups of equal image size, in order of first appearance."""
-    sizes = {}
-    for i, f in enumerate(filenames):
-        with Image.open(os.path.join(image_dir, f)) as im:
-            sizes.setdefault(im.size, []).append(i)
-    for idxs in sizes.values():
-        for lo in range(0, len(idxs), batch_size):
-            sel = idxs[lo:lo + batch_size]
-            yield sel, [filenames[i] for i in sel]
+def _batches(image_dir: str, filenames, batch_size: int, device):
+    """(row indices, uint8 [B,H,W,3] device tensor) per batch, decode and host-to-device copy running ahead of the
+    consumer (loader.ImageBatchLoader: same bytes, batches and order as the serial PIL loop it replaces)."""
+    for idxs, _, u8 in ImageBatchLoader(image_dir, filenames, batch_size, device):
+        yield idxs, u8
 
 
 @torch.no_grad()
@@ -76,8 +66,8 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
 
     filenames = df["filename"].tolist()
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
-    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
-        x = prep(_load_batch(image_dir, names, dev))
+    for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
+        x = prep(u8)
         preds_std[torch.tensor(idxs, device=dev)] = model(x)
     all_preds = scaler.inverse_transform(preds_std.cpu().numpy())                  # fp32 in -> fp32 out (:84)
     all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
@@ -109,8 +99,8 @@ def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, p
     prep = ResizeNormalize(224, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
     filenames = df["filename"].tolist()
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
-    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
-        preds_std[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(image_dir, names, dev)))
+    for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
+        preds_std[torch.tensor(idxs, device=dev)] = model(prep(u8))
     all_preds = scaler.inverse_transform(preds_std.cpu().numpy())
     all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
     final_loss = postproc.final_loss(all_preds, all_targets)                        # swin_validation.py:100
@@ -145,8 +135,8 @@ def _loadable(path: str) -> bool:
 @torch.no_grad()
 def _predict_files(model, image_dir: str, filenames, prep, scaler, batch_size: int, dev) -> np.ndarray:
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
-    for idxs, names in _batches_by_size(image_dir, filenames, batch_size):
-        preds_std[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(image_dir, names, dev)))
+    for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
+        preds_std[torch.tensor(idxs, device=dev)] = model(prep(u8))
     return scaler.inverse_transform(preds_std.cpu().numpy())
 
 
@@ -246,8 +236,8 @@ def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, 
 
     def predict_deg(directory, names):
         out = torch.empty((len(names), 2), dtype=torch.float32, device=dev)
-        for idxs, part in _batches_by_size(directory, names, batch_size):
-            out[torch.tensor(idxs, device=dev)] = model(prep(_load_batch(directory, part, dev))).float()
+        for idxs, u8 in _batches(directory, names, batch_size, dev):
+            out[torch.tensor(idxs, device=dev)] = model(prep(u8)).float()
         s, c = (out[:, 0], out[:, 1]) if order == "sincos" else (out[:, 1], out[:, 0])
         return ((torch.rad2deg(torch.atan2(s, c)) + 360.0) % 360.0).cpu().numpy()            # f32, as the script's tensors
 
@@ -298,8 +288,8 @@ def build_gallery_from_images(extractor: DinoV2Salad, csv_path: str, image_dir: 
     names = df["filename"].tolist()
     prep = ResizeNormalize(image_size, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
     desc = torch.empty((len(names), 8448), dtype=torch.float32, device=dev)
-    for idxs, part in _batches_by_size(image_dir, names, batch_size):
-        desc[torch.tensor(idxs, device=dev)] = extractor(prep(_load_batch(image_dir, part, dev)))
+    for idxs, u8 in _batches(image_dir, names, batch_size, dev):
+        desc[torch.tensor(idxs, device=dev)] = extractor(prep(u8))
     labels = df[list(G.LABEL_COLUMNS)].to_numpy(dtype=np.float64)
     if fp8:
         rows, scales = ops.quantize_fp8_rows(desc)
@@ -333,8 +323,8 @@ def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv
     kk = min(k, shard.n_total)
     vals = torch.empty((len(names), kk), dtype=torch.float32, device=dev)
     idx = torch.empty((len(names), kk), dtype=torch.int32, device=dev)
-    for idxs, part in _batches_by_size(image_dir, names, batch_size):
-        _, d16 = extractor.features(prep(_load_batch(image_dir, part, dev)), want_bf16=True)
+    for idxs, u8 in _batches(image_dir, names, batch_size, dev):
+        _, d16 = extractor.features(prep(u8), want_bf16=True)
         v, i = sg.search_local_queries(d16, kk)
         sel = torch.tensor(idxs, device=dev)
         vals[sel], idx[sel] = v, i
