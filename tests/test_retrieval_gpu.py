@@ -158,3 +158,24 @@ def test_pipeline_graph_retrieval_equals_eager(rccl_one_rank, fp8):
         assert torch.equal(a.pose, b.pose) and torch.equal(a.descriptors, b.descriptors)
     assert len(graphed.knn_events) == 3 and len(graphed._graphed) == 1
     assert graphed.gallery.uncertified_queries() == 0
+
+
+def test_sharded_gallery_exact_fallback_fixes_flagged_queries(dev):
+    """ShardedGallery(exact_fallback=True) — what evaluate.calculate_retrieval_scores uses: a query whose certificate
+    fails (64 near-tied rows in one level-0 chunk, test_knn_gpu._near_tie_problem) comes back exact; the device counter
+    still records that it was flagged; the graphed form refuses the option."""
+    from oracle import knn as oknn
+    from test_knn_gpu import _near_tie_problem
+    from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
+    q, gal, rows = _near_tie_problem(3, 64)
+    k = 10
+    v_ref, i_ref = oknn.knn_topk(q, gal, k)
+    bound = float(gal.float().norm(dim=1).max()) * 1.001
+    plain = ShardedGallery(gal.to(dev), gal.shape[0], norm_bound=bound)
+    plain.search(q.to(dev), k)
+    assert plain.uncertified_queries() == 1
+    sg = ShardedGallery(gal.to(dev), gal.shape[0], norm_bound=bound, exact_fallback=True)
+    v, i = sg.search(q.to(dev), k)
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref) and sg.uncertified_queries() == 1
+    with pytest.raises(RuntimeError, match="not capturable"):
+        GraphedRetrieval(sg, 2, k)

@@ -316,7 +316,8 @@ def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv
     dev = torch.device(device)
     extractor = extractor.to(dev).to(torch.bfloat16).eval()
     shard = G.load_gallery_shard(gallery_dir, dev, rank, world)
-    sg = ShardedGallery(shard.rows, shard.n_total, rank, world, group=group, scales=shard.scales)
+    # offline evaluation: unconditionally exact neighbours (queries the device certificate flags are re-run on f64 scores)
+    sg = ShardedGallery(shard.rows, shard.n_total, rank, world, group=group, scales=shard.scales, exact_fallback=True)
     df = _existing_rows(val_csv_path, image_dir)
     names = df["filename"].tolist()
     prep = ResizeNormalize(image_size, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
@@ -339,7 +340,7 @@ def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv
            "maae": postproc.mean_absolute_angular_error(pose[:, 2], df["angle"].to_numpy(dtype=np.float64)),
            "recall_at_1_tau": postproc.recall_at_k(top[:, :1], pos_d), f"recall_at_{kk}_tau": postproc.recall_at_k(top, pos_d),
            "recall_at_1_region": postproc.recall_at_k(top[:, :1], pos_r),
-           "uncertified_queries": sg.uncertified_queries()}
+           "uncertified_queries": sg.uncertified_queries()}        # flagged on the device (and re-run exactly), for the record
     if verbose:
         print(f"final_loss: {res['final_loss']}")
         print(f"Mean Absolute Angular Error (MAAE): {res['maae']:.4f} degrees")

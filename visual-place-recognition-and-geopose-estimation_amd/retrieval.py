@@ -28,20 +28,21 @@ class HipEngine:
     """Local top-k and merge on the gfx950 kernels."""
 
     def local_topk(self, q, gallery, k, index_base, scales=None, norm_bound=None, uncertified=None, ws=None,
-                   score_events=None):
+                   score_events=None, exact_fallback=False):
         """bf16 shard: q bf16.  fp8 shard (uint8 rows + per-row f32 `scales`): the gathered queries are
         quantised per row here (e4m3 + scale, vpr_quantize_fp8_rows) and searched by vpr_knn_topk_fp8.
         `uncertified` (int32 [1] on the device) counts queries whose answer the kernels could not certify as the
-        exact top-k (include/vpr_amd.h "Checked forms"); no host sync.  score_events: see ops.knn_topk."""
+        exact top-k (include/vpr_amd.h "Checked forms"); no host sync.  score_events: see ops.knn_topk.
+        exact_fallback: read the per-query status back (one sync) and re-run flagged queries exhaustively."""
         if gallery.dtype == torch.uint8:
             if scales is None:
                 raise ValueError("fp8 shard needs per-row scales")
             q8, qs = ops.quantize_fp8_rows(q.float())
             return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base, ws,
                                     norm_bound=norm_bound or ops.NORM_BOUND_FP8, uncertified=uncertified,
-                                    score_events=score_events)
+                                    score_events=score_events, exact_fallback=exact_fallback)
         return ops.knn_topk(q, gallery, k, index_base, ws, norm_bound=norm_bound or ops.NORM_BOUND_BF16,
-                            uncertified=uncertified, score_events=score_events)
+                            uncertified=uncertified, score_events=score_events, exact_fallback=exact_fallback)
 
     def merge(self, vals, idxs):
         return ops.topk_merge(vals, idxs)
@@ -62,12 +63,15 @@ def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
 class ShardedGallery:
     def __init__(self, local_rows: torch.Tensor, n_total: int, rank: int = 0, world: int = 1,
                  engine=None, group: Optional[dist.ProcessGroup] = None, scales: Optional[torch.Tensor] = None,
-                 norm_bound: Optional[float] = None, force_collectives: bool = False):
+                 norm_bound: Optional[float] = None, force_collectives: bool = False, exact_fallback: bool = False):
         """local_rows: [n_local, D] bf16, or uint8 e4m3 bytes with per-row f32 `scales` (value = scale * fp8).
         norm_bound: upper bound of the (dequantised) row norms for the exactness certificate; None = L2-normalised
         descriptors (what SALAD emits); `measure_norm_bound()` computes it from the rows.
         force_collectives: run the two all-gathers and the merge even with one rank (exercises the RCCL path on a
-        single GPU: bench.py --force-dist)."""
+        single GPU: bench.py --force-dist).
+        exact_fallback: every local search reads its certificate back (one host sync per search) and re-runs the
+        queries it could not certify on exact f64 scores — unconditionally exact answers, for offline evaluation; the
+        serving path leaves it off and watches `uncertified_queries()` instead (not capturable in a HIP graph)."""
         lo, hi = shard_bounds(n_total, rank, world)
         if local_rows.shape[0] != hi - lo:
             raise ValueError(f"rank {rank}: shard has {local_rows.shape[0]} rows, expected {hi - lo}")
@@ -81,6 +85,7 @@ class ShardedGallery:
         self.engine = engine if engine is not None else HipEngine()
         self.group = group
         self.norm_bound = norm_bound
+        self.exact_fallback = exact_fallback
         self.collective = world > 1 or force_collectives
         # queries whose local answer was not certified exact, summed over every search of this object (device word)
         self.uncertified = torch.zeros(1, dtype=torch.int32, device=local_rows.device) if local_rows.is_cuda else None
@@ -105,7 +110,7 @@ class ShardedGallery:
     def _local(self, q_all: torch.Tensor, k: int, ws=None, score_events=None):
         if isinstance(self.engine, HipEngine):
             return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales, self.norm_bound,
-                                          self.uncertified, ws, score_events)
+                                          self.uncertified, ws, score_events, self.exact_fallback)
         if self.scales is not None:
             return self.engine.local_topk(q_all, self.rows, k, self.index_base, self.scales)
         return self.engine.local_topk(q_all, self.rows, k, self.index_base)
@@ -141,6 +146,8 @@ class GraphedRetrieval:
 
     def __init__(self, gallery: ShardedGallery, batch_local: int, k: int):
         self.g, self.k, self.b = gallery, k, batch_local
+        if gallery.exact_fallback:
+            raise RuntimeError("GraphedRetrieval: exact_fallback reads the certificate back on the host — not capturable")
         if gallery.collective and dist.get_backend(gallery.group) != "nccl":
             raise RuntimeError("GraphedRetrieval: collectives can only be captured on the RCCL ('nccl') backend; "
                                f"this process group is '{dist.get_backend(gallery.group)}' — use the eager search")
