@@ -41,8 +41,9 @@ def run(gen, consume=None):
 
 
 print(f"decode only: serial {run(serial()):8.0f} images/s", flush=True)
-for w in (2, 4, 8, 15):
-    print(f"decode only: loader workers={w:2d} {run(u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w)):8.0f} images/s", flush=True)
+for export in ("raw", "arrow"):
+    for w in (2, 4, 8, 15):
+        print(f"decode only: loader export={export:5s} workers={w:2d} {run(u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w, export=export)):8.0f} images/s", flush=True)
 
 ext = DinoV2Salad("vit_large").to(dev).to(torch.bfloat16).eval()
 ext.backbone.fold_layerscale()
@@ -51,8 +52,8 @@ with torch.no_grad():
     step = lambda u8: ext(prep(u8))
     step(next(serial()))
     print(f"with ViT-L/14 + SALAD: serial {run(serial(), step):8.0f} images/s", flush=True)
-    for w in (4, 8):
-        print(f"with ViT-L/14 + SALAD: loader workers={w:2d} {run((u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w)), step):8.0f} images/s", flush=True)
+    for export, w in (("raw", 8), ("arrow", 8), ("arrow", 15)):
+        print(f"with ViT-L/14 + SALAD: loader export={export:5s} workers={w:2d} {run((u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w, export=export)), step):8.0f} images/s", flush=True)
 for f in names:
     os.remove(os.path.join(tmp, f))
 os.rmdir(tmp)

@@ -14,7 +14,14 @@ def _write_images(tmp_path, n, sizes=((64, 48), (32, 32))):
         W, H = sizes[(i // 3) % len(sizes)]                       # runs of 3 per size: groups interleave in the file list
         arr = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         name = f"im_{i:03d}.{'png' if i % 2 else 'jpg'}"
-        Image.fromarray(arr).save(os.path.join(tmp_path, name), quality=90)
+        img = Image.fromarray(arr)
+        if i % 7 == 3:
+            img, name = img.convert("L"), f"im_{i:03d}.png"            # grey, RGBA and palette files go through convert("RGB")
+        elif i % 11 == 5:
+            img, name = img.convert("RGBA"), f"im_{i:03d}.png"
+        elif i % 13 == 6:
+            img, name = img.convert("P"), f"im_{i:03d}.png"
+        img.save(os.path.join(tmp_path, name), quality=90)
         names.append(name)
     return names
 
@@ -23,16 +30,16 @@ def _serial(image_dir, names):
     return {f: np.asarray(Image.open(os.path.join(image_dir, f)).convert("RGB")) for f in names}
 
 
-@pytest.mark.parametrize("workers,depth", [(1, 1), (4, 3), (8, 2)])
-def test_loader_equals_serial_decode(tmp_path, workers, depth):
+@pytest.mark.parametrize("workers,depth,export", [(1, 1, "raw"), (4, 3, "raw"), (8, 2, "auto"), (4, 2, "arrow")])
+def test_loader_equals_serial_decode(tmp_path, workers, depth, export):
     from vpr_amd.loader import ImageBatchLoader, batches_by_size
     names = _write_images(str(tmp_path), 23)
     ref = _serial(str(tmp_path), names)
     plan = batches_by_size(str(tmp_path), names, 4)
     assert [s for s, _, _ in plan][:2] == [(64, 48)] * 2           # first size first, in order of first appearance
     seen = []
-    ld = ImageBatchLoader(str(tmp_path), names, 4, "cpu", workers=workers, depth=depth)
-    assert len(ld) == len(plan)
+    ld = ImageBatchLoader(str(tmp_path), names, 4, "cpu", workers=workers, depth=depth, export=export)
+    assert len(ld) == len(plan) and ld.export == ("arrow" if export == "arrow" else "raw")      # auto on a CPU device: raw
     for (size, idxs_p, names_p), (idxs, bnames, u8) in zip(plan, ld):
         assert idxs == idxs_p and bnames == names_p
         assert u8.dtype == torch.uint8 and tuple(u8.shape) == (len(idxs), size[1], size[0], 3)

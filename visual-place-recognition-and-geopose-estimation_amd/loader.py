@@ -6,11 +6,13 @@ The reference feeds its models from a `DataLoader` (`dinov2salad/dinov2salad_val
 left on the host is the image decode — ~1-2 ms per JPEG, i.e. 10x the GPU time of a 64-image step if done serially.
 `ImageBatchLoader` keeps `depth` batches ahead of the consumer:
 
-  * a thread pool decodes (PIL releases the GIL inside its codecs) straight into slots of a pinned host buffer.
+  * a thread pool decodes (PIL releases the GIL inside its codecs) straight into slots of a pinned host buffer.  What
+    caps threads is the GIL-held part of a decode: PIL's raw export packs its 4-byte RGBX pixels to 3 under the lock
+    (~0.4 ms per VGA frame).  With pyarrow present the pixel storage is handed over zero-copy (Arrow C data interface,
+    8 us) and copied with one GIL-free memcpy as RGBX; the fourth byte is dropped on the GPU.  `scripts/loader_bench.py`,
+    1536 VGA JPEGs, decode + copy: serial 0.64k images/s, 8 threads 2.5k (raw export) / 4.3k (Arrow hand-over).
     Worker PROCESSES (a `DataLoader` over the same plan) were measured and dropped: forking 8-15 workers from a process
-    that holds the GPU context costs seconds, and they deliver 0.4-1.4k images/s on a 1536-image list against 2.5-3.0k
-    for 4-8 threads (640x480 JPEGs; serial loop: 0.64k).  What caps the threads at ~3k images/s is the part of a decode
-    that holds the GIL (PIL's raw export of the decoded image, ~0.3 ms per VGA frame) — `scripts/loader_bench.py`,
+    that holds the GPU context costs seconds; 0.4-1.4k images/s on the same list,
   * a finished batch goes to the device with one asynchronous copy on a dedicated copy stream,
   * the consumer's stream waits on that copy's event only — no host sync, the previous batch's kernels keep running.
 
@@ -30,6 +32,11 @@ import numpy as np
 import torch
 from PIL import Image
 
+try:
+    import pyarrow as _pa
+except ImportError:                                              # the raw export path needs nothing but PIL
+    _pa = None
+
 
 def batches_by_size(image_dir: str, filenames: Sequence[str], batch_size: int) -> List[Tuple[Tuple[int, int], List[int], List[str]]]:
     """[((W, H), row indices, filenames)] groups of equal image size, sizes in order of first appearance."""
@@ -46,24 +53,52 @@ def batches_by_size(image_dir: str, filenames: Sequence[str], batch_size: int) -
 
 
 def _decode_into(path: str, slot: np.ndarray) -> None:
+    """slot [H,W,3]: PIL's raw export (one pass under the GIL that packs its 4-byte RGBX pixels to 3) + a copy.
+    slot [H,W,4]: PIL's pixel storage itself, handed over zero-copy through the Arrow C data interface and copied with
+    one GIL-free memcpy; the X byte is dropped on the GPU."""
     with Image.open(path) as im:
-        arr = np.asarray(im if im.mode == "RGB" else im.convert("RGB"))      # convert() of an RGB image is a plain copy
-    if arr.shape != slot.shape:
-        raise RuntimeError(f"{path}: decoded to {arr.shape}, its header promised {slot.shape}")
-    np.copyto(slot, arr)
+        rgb = im if im.mode == "RGB" else im.convert("RGB")                 # convert() of an RGB image is a plain copy
+        if slot.shape[-1] == 4:
+            rgb.load()
+            arr = _pa.array(rgb).values.to_numpy(zero_copy_only=True).reshape(rgb.size[1], rgb.size[0], 4)
+        else:
+            arr = np.asarray(rgb)
+        if arr.shape != slot.shape:
+            raise RuntimeError(f"{path}: decoded to {arr.shape}, its header promised {slot.shape}")
+        np.copyto(slot, arr)
+
+
+def _arrow_export_works() -> bool:
+    """Pillow >= 11.2 exports an RGB image as fixed_size_list<uint8>[4] over its own storage; probe once."""
+    if _pa is None:
+        return False
+    try:
+        im = Image.new("RGB", (3, 2), (1, 2, 3))
+        v = _pa.array(im).values.to_numpy(zero_copy_only=True).reshape(2, 3, 4)
+        return bool((v[..., :3] == np.array([1, 2, 3], dtype=np.uint8)).all())
+    except Exception:                                            # noqa: BLE001  any failure = the raw export path
+        return False
 
 
 class ImageBatchLoader:
     """Iterate `(row indices, filenames, uint8 [B,H,W,3] tensor on `device`)` with decode and H2D copy running ahead."""
 
     def __init__(self, image_dir: str, filenames: Sequence[str], batch_size: int, device, *,
-                 workers: Optional[int] = None, depth: int = 3):
+                 workers: Optional[int] = None, depth: int = 3, export: str = "auto"):
+        """export: how a decoded image leaves PIL — "raw" (np.asarray: a packing pass under the GIL), "arrow" (zero-copy
+        RGBX hand-over + GIL-free memcpy, the fourth byte dropped on the device; needs pyarrow and Pillow >= 11.2) or
+        "auto" (arrow on a CUDA device when it works)."""
+        if export not in ("auto", "raw", "arrow"):
+            raise ValueError("export must be 'auto', 'raw' or 'arrow'")
         self.image_dir, self.device = image_dir, torch.device(device)
         self.filenames = list(filenames)
         self.plan = batches_by_size(image_dir, self.filenames, batch_size)
         self.workers = workers if workers is not None else max(1, min(8, (os.cpu_count() or 2) - 1))   # more than 8 lose to the GIL
         self.depth = max(1, depth)
         self._cuda = self.device.type == "cuda"
+        if export == "arrow" and not _arrow_export_works():
+            raise RuntimeError("export='arrow' needs pyarrow and a Pillow with the Arrow C data interface")
+        self.export = export if export != "auto" else ("arrow" if self._cuda and _arrow_export_works() else "raw")
 
     def __len__(self) -> int:
         return len(self.plan)
@@ -107,7 +142,7 @@ class ImageBatchLoader:
                 if item is None:
                     return False
                 (W, H), idxs, names = item
-                shape = (len(names), H, W, 3)
+                shape = (len(names), H, W, 4 if self.export == "arrow" else 3)
                 buf = self._host_buffer(ring, shape)
                 slot_of = ring[shape]["cur"]
                 view = buf.numpy()
@@ -127,5 +162,7 @@ class ImageBatchLoader:
                     ring[shape]["events"][slot_of] = ev
                 else:
                     dev_t = buf.clone()
+                if shape[-1] == 4:
+                    dev_t = dev_t[..., :3].contiguous()          # RGBX -> RGB on the consumer's stream (after the copy's event)
                 launch()                                         # keep `depth` batches decoding while the consumer computes
                 yield idxs, names, dev_t
