@@ -1,4 +1,4 @@
-"""Experiment: capture the HIP backbone path (with its cls side stream) into one HIP graph and replay it."""
+"""Experiment: capture the HIP backbone path (with and without its cls side stream) into one HIP graph and replay it."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpr_amd.modules import DinoV2Salad
@@ -17,18 +17,21 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     return (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3
-ref = ext.backbone(x, split=True)
-print("eager    enqueue %.2f ms  total %.2f ms" % timeit(lambda: ext.backbone(x, split=True)))
-s = torch.cuda.Stream(device=dev)
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(2): ext.backbone(x, split=True)          # warm this stream's buffers / side stream
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g, stream=s):
-    out = ext.backbone(x, split=True)
-torch.cuda.synchronize()
-g.replay(); torch.cuda.synchronize()
-print("graph == eager:", torch.equal(out.patch, ref.patch), torch.equal(out.cls, ref.cls))
-print("replay   enqueue %.2f ms  total %.2f ms" % timeit(lambda: g.replay()))
+for side in (True, False):
+    ext.backbone.cls_side_chain = side
+    print(f"--- cls rows on a side stream: {side}")
+    ref = ext.backbone(x, split=True)
+    print("eager    enqueue %.2f ms  total %.2f ms" % timeit(lambda: ext.backbone(x, split=True)))
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2): ext.backbone(x, split=True)          # warm this stream's buffers / side stream
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out = ext.backbone(x, split=True)
+    torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    print("graph == eager:", torch.equal(out.patch, ref.patch), torch.equal(out.cls, ref.cls))
+    print("replay   enqueue %.2f ms  total %.2f ms" % timeit(lambda: g.replay()))

@@ -54,6 +54,13 @@ with torch.no_grad():
     print(f"with ViT-L/14 + SALAD: serial {run(serial(), step):8.0f} images/s", flush=True)
     for export, w in (("raw", 8), ("arrow", 8), ("arrow", 15)):
         print(f"with ViT-L/14 + SALAD: loader export={export:5s} workers={w:2d} {run((u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w, export=export)), step):8.0f} images/s", flush=True)
+    from vpr_amd.graphed import GraphedForward
+    gext = GraphedForward(ext)
+    gstep = lambda u8: gext(prep(u8))
+    gstep(next(serial()))
+    print(f"with ViT-L/14 + SALAD replayed from a HIP graph: serial {run(serial(), gstep):8.0f} images/s", flush=True)
+    for export, w in (("raw", 8), ("arrow", 8), ("arrow", 12)):
+        print(f"with ViT-L/14 + SALAD replayed from a HIP graph: loader export={export:5s} workers={w:2d} {run((u8 for _, _, u8 in ImageBatchLoader(tmp, names, B, dev, workers=w, export=export)), gstep):8.0f} images/s", flush=True)
 for f in names:
     os.remove(os.path.join(tmp, f))
 os.rmdir(tmp)

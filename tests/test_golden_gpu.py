@@ -387,3 +387,31 @@ def test_image_batch_loader_on_gpu_equals_serial_decode(dev, tmp_path):
             assert np.array_equal(host[j], ref[f]) and names[idxs[j]] == f
         seen += len(idxs)
     assert seen == len(names)
+
+
+def test_graphed_forward_equals_eager(dev):
+    """vpr_amd.graphed.GraphedForward: the extractor / regression model forward replayed from a HIP graph (one per input
+    shape; the DINOv2 cls side stream switched off inside the capture) returns the eager forward's bits, batch after
+    batch, with batch sizes interleaved and growing (3, 6, 9: later captures need larger workspaces and other
+    batch-size-keyed constants — whatever an earlier graph addresses must stay allocated; an earlier version replaced
+    those cache entries and the first graph then read freed memory: cosine 0.985 against the eager descriptor)."""
+    from vpr_amd.graphed import GraphedForward
+    from vpr_amd.modules import DINOv2RegressionModel, DinoV2Salad
+    torch.manual_seed(3)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    model = DINOv2RegressionModel(ext).to(dev).eval()
+    fwd = GraphedForward(model)
+    feats = GraphedForward(lambda x: ext.features(x, want_bf16=True), module=ext)
+    g = torch.Generator(device=dev).manual_seed(0)
+    for trial, B in enumerate((3, 6, 3, 6, 3, 9, 3, 6, 9)):
+        x = torch.randn(B, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
+        with torch.no_grad():
+            ref = model(x)
+            d_ref, d16_ref = ext.features(x, want_bf16=True)
+        out = fwd(x)
+        assert torch.equal(out, ref), trial
+        d, d16 = feats(x)
+        assert torch.equal(d, d_ref) and torch.equal(d16, d16_ref), trial
+    assert fwd.graphs() == 3 and feats.graphs() == 3
+    assert ext.backbone.cls_side_chain is True                  # restored after every captured / replayed call

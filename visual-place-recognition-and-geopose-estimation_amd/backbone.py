@@ -207,7 +207,13 @@ class DinoV2(nn.Module):
         pe = self.patch_embed
         key = (str(img.device), B, kpad, pe.weight.data_ptr(), pe.weight._version, pe.bias._version,
                self.pos_embed.data_ptr(), self.pos_embed._version, self.cls_token._version)
-        if getattr(self, "_embed_key", None) != key:
+        # one entry per batch size (an evaluation loop alternates between its full and its last, ragged batch); an entry
+        # a HIP graph was captured on is pinned: the graph addresses its tensors for as long as it is replayed
+        cache = self.__dict__.setdefault("_embed_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            for k in [k for k, e in cache.items() if not e[2]][: max(0, len(cache) - 3)]:
+                del cache[k]
             dev = img.device
             w = torch.zeros((C, kpad), dtype=torch.bfloat16, device=dev)
             w[:, :K] = pe.weight.detach().reshape(C, K).to(dev, torch.bfloat16)
@@ -216,8 +222,10 @@ class DinoV2(nn.Module):
             tail = (pos[0] + self.cls_token.detach().float().to(dev).view(C)).to(torch.bfloat16)
             off = torch.cat([body.unsqueeze(0).expand(B, -1, -1).reshape(B * n, C),
                              tail.unsqueeze(0).expand(B, -1)], dim=0).contiguous()
-            self._embed_w, self._embed_off, self._embed_key = w, off, key
-        return self._embed_w, self._embed_off
+            ent = cache[key] = [w, off, False]
+        if not ent[2] and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            ent[2] = True
+        return ent[0], ent[1]
 
     cls_side_chain = True
 
@@ -288,12 +296,15 @@ class DinoV2(nn.Module):
     def _raw_tokens(self, M: int, Mp: int, C: int, dev: torch.device) -> torch.Tensor:
         bufs = self.__dict__.setdefault("_raw_bufs", {})     # per (device, stream, shape): two streams never share it
         key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, M, C)
-        buf = bufs.get(key)
-        if buf is None:
+        ent = bufs.get(key)
+        if ent is None:
             if len(bufs) > 8:
-                bufs.clear()
-            buf = bufs[key] = torch.zeros((M, C), dtype=torch.bfloat16, device=dev)
-        return buf
+                for k in [k for k, e in bufs.items() if not e[1]]:       # entries a HIP graph addresses stay
+                    del bufs[k]
+            ent = bufs[key] = [torch.zeros((M, C), dtype=torch.bfloat16, device=dev), False]
+        if not ent[1] and torch.cuda.is_current_stream_capturing():
+            ent[1] = True
+        return ent[0]
 
     def _forward_hip_split(self, img: torch.Tensor) -> "SplitTokens":
         """The whole backbone on the GPU in the split row layout [B*n patch rows | B cls rows]:

@@ -24,6 +24,7 @@ import torch
 from PIL import Image
 
 from . import postproc, reports
+from .graphed import GraphedForward
 from .loader import ImageBatchLoader
 from .modules import DINOv2RegressionModel, DinoV2Salad, load_reference_checkpoint
 from .preprocess import HALF_MEAN, HALF_STD, IMAGENET_MEAN, IMAGENET_STD, ResizeNormalize
@@ -48,7 +49,7 @@ def _batches(image_dir: str, filenames, batch_size: int, device):
 def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_dir: str, *,
                                 base_model: Optional[DinoV2Salad] = None, arch: str = "vit_base",
                                 scaler: Optional[postproc.LatLonScaler] = None, batch_size: int = 16,
-                                device: str = "cuda", verbose: bool = True) -> dict:
+                                device: str = "cuda", verbose: bool = True, graph: bool = True) -> dict:
     df = _existing_rows(val_csv_path, image_dir)
     dev = torch.device(device)
     if base_model is None:
@@ -66,9 +67,11 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
 
     filenames = df["filename"].tolist()
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    # one HIP-graph launch per batch instead of ~300 kernel launches: the host (and its GIL) belongs to the decode threads
+    fwd = GraphedForward(model) if graph and dev.type == "cuda" else model
     for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
         x = prep(u8)
-        preds_std[torch.tensor(idxs, device=dev)] = model(x)
+        preds_std[torch.tensor(idxs, device=dev)] = fwd(x)
     all_preds = scaler.inverse_transform(preds_std.cpu().numpy())                  # fp32 in -> fp32 out (:84)
     all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
     final_loss = postproc.final_loss(all_preds, all_targets)                        # :101
@@ -277,7 +280,7 @@ def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, 
 # directory conventions as the validation scripts, with the gallery built from the training split.
 @torch.no_grad()
 def build_gallery_from_images(extractor: DinoV2Salad, csv_path: str, image_dir: str, out_dir: str, *, fp8: bool = False,
-                              batch_size: int = 64, device: str = "cuda", image_size: int = 224) -> int:
+                              batch_size: int = 64, device: str = "cuda", image_size: int = 224, graph: bool = True) -> int:
     """labels CSV (`filename,timestamp,latitude,longitude,angle,Region_ID`, cleaned_dataset_files/labels_train.csv:1) +
     images -> on-disk gallery (gallery.save_gallery: bf16 rows, or e4m3 rows + per-row scales with fp8=True).
     Preprocessing = the DINOv2+SALAD validation transform (dinov2salad_validation.py:18-22).  Returns the row count."""
@@ -288,8 +291,9 @@ def build_gallery_from_images(extractor: DinoV2Salad, csv_path: str, image_dir: 
     names = df["filename"].tolist()
     prep = ResizeNormalize(image_size, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
     desc = torch.empty((len(names), 8448), dtype=torch.float32, device=dev)
+    fwd = GraphedForward(extractor) if graph and dev.type == "cuda" else extractor
     for idxs, u8 in _batches(image_dir, names, batch_size, dev):
-        desc[torch.tensor(idxs, device=dev)] = extractor(prep(u8))
+        desc[torch.tensor(idxs, device=dev)] = fwd(prep(u8))
     labels = df[list(G.LABEL_COLUMNS)].to_numpy(dtype=np.float64)
     if fp8:
         rows, scales = ops.quantize_fp8_rows(desc)
@@ -301,7 +305,7 @@ def build_gallery_from_images(extractor: DinoV2Salad, csv_path: str, image_dir: 
 
 @torch.no_grad()
 def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv_path: str, image_dir: str, *, k: int = 10,
-                               tau: float = 25.0, mode: str = "top1", batch_size: int = 64, device: str = "cuda",
+                               tau: float = 25.0, mode: str = "top1", batch_size: int = 64, device: str = "cuda", graph: bool = True,
                                image_size: int = 224, rank: int = 0, world: int = 1, group=None, verbose: bool = True) -> dict:
     """Validation split through descriptor -> sharded cosine top-k -> label transfer:
       pose      (lat, lon, angle) of the best match, or the softmax-weighted mean of the k matches (gallery.label_transfer);
@@ -324,8 +328,10 @@ def calculate_retrieval_scores(extractor: DinoV2Salad, gallery_dir: str, val_csv
     kk = min(k, shard.n_total)
     vals = torch.empty((len(names), kk), dtype=torch.float32, device=dev)
     idx = torch.empty((len(names), kk), dtype=torch.int32, device=dev)
+    features = lambda x: extractor.features(x, want_bf16=True)
+    fwd = GraphedForward(features, module=extractor) if graph and dev.type == "cuda" else features
     for idxs, u8 in _batches(image_dir, names, batch_size, dev):
-        _, d16 = extractor.features(prep(u8), want_bf16=True)
+        _, d16 = fwd(prep(u8))
         v, i = sg.search_local_queries(d16, kk)
         sel = torch.tensor(idxs, device=dev)
         vals[sel], idx[sel] = v, i

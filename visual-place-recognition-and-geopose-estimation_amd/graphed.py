@@ -1,0 +1,83 @@
+"""Replay a model forward from a HIP graph, one graph per input shape.
+
+The evaluation / gallery-building loops are host-bound once the GPU path is in place: a ViT-L/14 + SALAD forward is
+~300 kernel launches = 4-6 ms of Python under the GIL per batch, the same lock the image-decode threads
+(`loader.ImageBatchLoader`) need.  Captured once per input shape, the forward is ONE graph launch (0.1 ms of host time,
+same GPU time as the eager in-stream forward: `scripts/graph_backbone.py`).
+
+Capture rules the wrapped function must obey (the HIP paths of this package do): no host sync, no `.item()`/`.cpu()`,
+workspaces from `ops.workspace` (allocated during the warm-up calls, outside capture).  The DINOv2 backbone's cls-row
+side stream is switched off inside the captured forward: fork / join branches replay slower than the eager side stream
+(16.2 vs 10.9 ms) while the linear chain replays at the eager in-stream time (11.3 ms); results are bit-identical
+either way (`test_cls_side_chain_is_bit_identical_to_in_stream_path`, `test_graphed_forward_equals_eager`).
+
+A captured graph addresses its operands by raw pointer, including what the package caches between calls (workspaces,
+packed weights, batch-size-keyed backbone constants).  Those caches pin every entry that is handed out while a capture
+is in progress (`ops.capturing()`): a pinned entry is never freed or replaced in place, so graphs of several input
+shapes and eager calls can be interleaved freely.
+
+The returned tensors are the graph's static output buffers: valid until the next call with the same input shape —
+consume (or clone) them before that, on the stream the call was made on.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Tuple
+
+import torch
+
+
+def _backbones(obj) -> list:
+    """DinoV2 backbones reachable from a module (their cls side chain is disabled while a graph is captured)."""
+    out = []
+    if isinstance(obj, torch.nn.Module):
+        for m in obj.modules():
+            if hasattr(m, "cls_side_chain"):
+                out.append(m)
+    return out
+
+
+class GraphedForward:
+    def __init__(self, fn: Callable[[torch.Tensor], object], module: torch.nn.Module = None, warmup: int = 2):
+        """fn(x) -> tensor or (nested) tuple of tensors.  `module` (optional): where to look for DINOv2 backbones whose
+        side stream has to be off during capture (defaults to fn if it is a module)."""
+        self.fn, self.warmup = fn, max(1, warmup)
+        self._backbones = _backbones(module if module is not None else fn)
+        self._graphs: Dict[Tuple, Tuple] = {}
+
+    def _run(self, x):
+        saved = [b.cls_side_chain for b in self._backbones]
+        for b in self._backbones:
+            b.cls_side_chain = False
+        try:
+            with torch.no_grad():
+                return self.fn(x)
+        finally:
+            for b, s in zip(self._backbones, saved):
+                b.cls_side_chain = s
+
+    def __call__(self, x: torch.Tensor):
+        if not x.is_cuda:
+            return self._run(x)
+        key = (tuple(x.shape), x.dtype, x.device.index)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = x.clone()
+            cur = torch.cuda.current_stream(x.device)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                      # warm-up outside capture: workspaces, module load, plane caches
+                for _ in range(self.warmup):
+                    self._run(static_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._run(static_in)
+            entry = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(x)
+        graph.replay()
+        return static_out
+
+    def graphs(self) -> int:
+        return len(self._graphs)

@@ -44,16 +44,29 @@ def _need(t: torch.Tensor, dtype: torch.dtype, name: str, ndim: Optional[int] = 
         raise RuntimeError(f"{name}: expected {ndim} dims, got {t.dim()}")
 
 
+def capturing() -> bool:
+    """True while the current stream records into a HIP graph: whatever a cache hands out now is baked into the graph
+    as a raw address and must stay allocated for as long as the graph may be replayed."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+_GRAPH_PINNED: list = []       # buffers a captured graph addresses, kept alive when their cache entry is replaced
+
+
 def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
     """Cached byte buffer per (device, stream, name); grows, never shrinks.  Keyed by the current stream so that
-    two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory."""
+    two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory.  A buffer
+    handed out during graph capture is never freed (a later, larger request gets a new one; the old stays pinned)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _raw_stream(idx), name)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        _WORKSPACES[key] = buf
-    return buf
+    ent = _WORKSPACES.get(key)
+    if ent is None or ent[0].numel() < nbytes:
+        if ent is not None and ent[1]:
+            _GRAPH_PINNED.append(ent[0])
+        ent = _WORKSPACES[key] = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device), False]
+    if not ent[1] and capturing():
+        ent[1] = True
+    return ent[0]
 
 
 # ------------------------------------------------------------------------------------------ SALAD
@@ -395,12 +408,16 @@ def _pose_w1_planes(W1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     hit = _POSE_PLANES.get(key)
     if hit is None:
         while len(_POSE_PLANES) >= 8:
-            _POSE_PLANES.pop(next(iter(_POSE_PLANES)))        # oldest first (dicts keep insertion order)
+            old = _POSE_PLANES.pop(next(iter(_POSE_PLANES)))  # oldest first (dicts keep insertion order)
+            if old[3]:
+                _GRAPH_PINNED.append(old)                     # a captured graph reads these planes: never freed
         hi = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
         lo = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
         st = _lib.lib().vpr_pose_head_pack_w1(_ptr(W1), W1.numel(), _ptr(hi), _ptr(lo), _stream())
         _lib.check(st, "vpr_pose_head_pack_w1")
-        hit = _POSE_PLANES[key] = (hi, lo, W1)
+        hit = _POSE_PLANES[key] = [hi, lo, W1, False]
+    if not hit[3] and capturing():
+        hit[3] = True
     return hit[0], hit[1]
 
 
