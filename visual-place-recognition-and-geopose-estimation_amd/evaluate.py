@@ -38,6 +38,12 @@ def _existing_rows(val_csv_path: str, image_dir: str) -> pd.DataFrame:
     return filtered.reset_index(drop=True)
 
 
+def _graphed(model, dev: torch.device):
+    """The model forward as one HIP-graph replay per batch (graphed.GraphedForward; a forward that cannot be captured
+    falls back to the eager call by itself); the model itself on a CPU device."""
+    return GraphedForward(model) if dev.type == "cuda" else model
+
+
 def _batches(image_dir: str, filenames, batch_size: int, device):
     """(row indices, uint8 [B,H,W,3] device tensor) per batch, decode and host-to-device copy running ahead of the
     consumer (loader.ImageBatchLoader: same bytes, batches and order as the serial PIL loop it replaces)."""
@@ -90,7 +96,7 @@ def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_d
 @torch.no_grad()
 def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, preds_csv: Optional[str] = None, *,
                                      checkpoint_path: Optional[str] = None, scaler: Optional[postproc.LatLonScaler] = None,
-                                     batch_size: int = 16, device: str = "cuda", verbose: bool = True) -> dict:
+                                     batch_size: int = 16, device: str = "cuda", verbose: bool = True, graph: bool = True) -> dict:
     """`model`: a vpr_amd.modules.SwinRegressionModel (backbone object inside).  Preprocessing follows the
     HF Swin image processor: bicubic resize to 224, /255, ImageNet mean/std."""
     df = _existing_rows(val_csv_path, image_dir)
@@ -102,8 +108,9 @@ def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, p
     prep = ResizeNormalize(224, "bicubic", IMAGENET_MEAN, IMAGENET_STD, torch.float32)
     filenames = df["filename"].tolist()
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    fwd = _graphed(model, dev)             # Swin-T at batch 16 is launch-bound: the graph replay is 2x the eager forward
     for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
-        preds_std[torch.tensor(idxs, device=dev)] = model(prep(u8))
+        preds_std[torch.tensor(idxs, device=dev)] = fwd(prep(u8))
     all_preds = scaler.inverse_transform(preds_std.cpu().numpy())
     all_targets = df[["latitude", "longitude"]].to_numpy(dtype=np.float32)
     final_loss = postproc.final_loss(all_preds, all_targets)                        # swin_validation.py:100
@@ -138,8 +145,9 @@ def _loadable(path: str) -> bool:
 @torch.no_grad()
 def _predict_files(model, image_dir: str, filenames, prep, scaler, batch_size: int, dev) -> np.ndarray:
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)
+    fwd = _graphed(model, dev)
     for idxs, u8 in _batches(image_dir, filenames, batch_size, dev):
-        preds_std[torch.tensor(idxs, device=dev)] = model(prep(u8))
+        preds_std[torch.tensor(idxs, device=dev)] = fwd(prep(u8))
     return scaler.inverse_transform(preds_std.cpu().numpy())
 
 
@@ -239,8 +247,9 @@ def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, 
 
     def predict_deg(directory, names):
         out = torch.empty((len(names), 2), dtype=torch.float32, device=dev)
+        fwd = _graphed(model, dev)
         for idxs, u8 in _batches(directory, names, batch_size, dev):
-            out[torch.tensor(idxs, device=dev)] = model(prep(u8)).float()
+            out[torch.tensor(idxs, device=dev)] = fwd(prep(u8)).float()
         s, c = (out[:, 0], out[:, 1]) if order == "sincos" else (out[:, 1], out[:, 0])
         return ((torch.rad2deg(torch.atan2(s, c)) + 360.0) % 360.0).cpu().numpy()            # f32, as the script's tensors
 

@@ -43,6 +43,7 @@ class GraphedForward:
         self.fn, self.warmup = fn, max(1, warmup)
         self._backbones = _backbones(module if module is not None else fn)
         self._graphs: Dict[Tuple, Tuple] = {}
+        self.fallback_reason = None          # set when a capture failed: the wrapper then runs the eager forward for good
 
     def _run(self, x):
         saved = [b.cls_side_chain for b in self._backbones]
@@ -56,7 +57,7 @@ class GraphedForward:
                 b.cls_side_chain = s
 
     def __call__(self, x: torch.Tensor):
-        if not x.is_cuda:
+        if not x.is_cuda or self.fallback_reason is not None:
             return self._run(x)
         key = (tuple(x.shape), x.dtype, x.device.index)
         entry = self._graphs.get(key)
@@ -71,8 +72,13 @@ class GraphedForward:
             cur.wait_stream(side)
             torch.cuda.synchronize(x.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = self._run(static_in)
+            try:
+                with torch.cuda.graph(graph):
+                    static_out = self._run(static_in)
+            except Exception as e:                             # noqa: BLE001  a forward that cannot be captured (host sync, ...)
+                self.fallback_reason = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize(x.device)
+                return self._run(x)
             entry = self._graphs[key] = (graph, static_in, static_out)
         graph, static_in, static_out = entry
         static_in.copy_(x)
