@@ -415,3 +415,30 @@ def test_graphed_forward_equals_eager(dev):
         assert torch.equal(d, d_ref) and torch.equal(d16, d16_ref), trial
     assert fwd.graphs() == 3 and feats.graphs() == 3
     assert ext.backbone.cls_side_chain is True                  # restored after every captured / replayed call
+
+
+def test_cache_descriptors_from_images_equals_batchwise_extractor(dev, tmp_path):
+    """finetune.cache_descriptors_from_images (loader -> GPU preprocessing -> graphed extractor) == the extractor applied to
+    the same preprocessed images one batch at a time, rows in file-list order (mixed image sizes regroup the batches)."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from vpr_amd.finetune import cache_descriptors, cache_descriptors_from_images
+    from vpr_amd.modules import DinoV2Salad
+    from vpr_amd.preprocess import HALF_MEAN, HALF_STD, ResizeNormalize
+    rng = np.random.default_rng(5)
+    names = []
+    for i in range(11):
+        W, H = ((300, 260), (256, 256))[i % 2]
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(os.path.join(tmp_path, f"{i:02d}.png"))
+        names.append(f"{i:02d}.png")
+    torch.manual_seed(2)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    got = cache_descriptors_from_images(ext, str(tmp_path), names, batch_size=4, device=str(dev))
+    prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
+    one = lambda f: prep(torch.from_numpy(np.asarray(Image.open(os.path.join(tmp_path, f)).convert("RGB"))[None]).to(dev))
+    ref = cache_descriptors(ext, [one(f) for f in names])
+    assert got.shape == (11, 8448)
+    # batch composition differs (4 per size group vs 1): the GEMMs see other M -> compare to bf16 noise, row by row
+    assert torch.nn.functional.cosine_similarity(got, ref, dim=1).min().item() > 0.9999

@@ -30,6 +30,29 @@ def cache_descriptors(extractor: nn.Module, image_batches: Iterable[torch.Tensor
     return torch.cat([extractor(x).float() for x in image_batches])
 
 
+@torch.no_grad()
+def cache_descriptors_from_images(extractor: nn.Module, image_dir: str, filenames, *, batch_size: int = 64,
+                                  device: str = "cuda", prep=None) -> torch.Tensor:
+    """The same cache straight from image files, in file-list order: decode-ahead loader (loader.ImageBatchLoader) ->
+    GPU resize / normalise (the fine-tuning transform, dinov2salad_finetuning.py:45-50: 224 bilinear, mean = std = 0.5)
+    -> extractor forward replayed from one HIP graph per batch shape (graphed.GraphedForward)."""
+    from .graphed import GraphedForward
+    from .loader import ImageBatchLoader
+    from .preprocess import HALF_MEAN, HALF_STD, ResizeNormalize
+    dev = torch.device(device)
+    extractor = extractor.to(dev).eval()
+    prep = prep or ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)
+    fwd = GraphedForward(extractor) if dev.type == "cuda" else extractor
+    filenames = list(filenames)
+    out = None
+    for idxs, _, u8 in ImageBatchLoader(image_dir, filenames, batch_size, dev):
+        d = fwd(prep(u8)).float()
+        if out is None:
+            out = torch.empty((len(filenames), d.shape[1]), dtype=torch.float32, device=dev)
+        out[torch.tensor(idxs, device=dev)] = d
+    return out
+
+
 def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, labels: np.ndarray,
                   epochs: int = 100, batch_size: int = 16, lr: float = 1e-5, save_dir: Optional[str] = None,
                   val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print) -> dict:
