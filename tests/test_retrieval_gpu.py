@@ -179,3 +179,32 @@ def test_sharded_gallery_exact_fallback_fixes_flagged_queries(dev):
     assert torch.equal(i.cpu(), i_ref) and torch.equal(v.cpu(), v_ref) and sg.uncertified_queries() == 1
     with pytest.raises(RuntimeError, match="not capturable"):
         GraphedRetrieval(sg, 2, k)
+
+
+def test_whole_pipeline_step_replays_from_one_hip_graph(dev):
+    """The whole hot path — backbone, SALAD, kNN against the shard (certificate included), fused head — captured as ONE
+    HIP graph per batch shape (graphed.GraphedForward around VPRGeoPosePipeline.step) and replayed: bit-identical
+    StepOutput to the eager step, on fresh images each time."""
+    import torch.nn as nn
+    from vpr_amd.graphed import GraphedForward
+    from vpr_amd.modules import DinoV2Salad, FusedGeoPoseHead
+    from vpr_amd.pipeline import VPRGeoPosePipeline
+    from vpr_amd.retrieval import ShardedGallery
+    torch.manual_seed(4)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    pos = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    ang = nn.Sequential(nn.Linear(8448, 64), nn.ReLU(), nn.Linear(64, 2)).to(dev)
+    head = FusedGeoPoseHead(pos, ang, normalize=True)
+    gal = torch.nn.functional.normalize(torch.randn(9000, 8448, device=dev), dim=1).to(torch.bfloat16)
+    pipe = VPRGeoPosePipeline(ext, head, ShardedGallery(gal, 9000), 5)
+    step = GraphedForward(pipe.step, module=ext)
+    for trial in range(3):
+        images = torch.randn(8, 3, 224, 224, device=dev, generator=torch.Generator(device=dev).manual_seed(trial)).to(torch.bfloat16)
+        ref = pipe.step(images)
+        out = step(images)
+        torch.cuda.synchronize()
+        assert step.fallback_reason is None
+        assert torch.equal(out.topk_indices, ref.topk_indices) and torch.equal(out.topk_scores, ref.topk_scores), trial
+        assert torch.equal(out.pose, ref.pose) and torch.equal(out.descriptors, ref.descriptors), trial
+    assert step.graphs() == 1 and pipe.gallery.uncertified_queries() == 0
