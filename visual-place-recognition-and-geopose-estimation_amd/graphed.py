@@ -16,6 +16,9 @@ packed weights, batch-size-keyed backbone constants).  Those caches pin every en
 is in progress (`ops.capturing()`): a pinned entry is never freed or replaced in place, so graphs of several input
 shapes and eager calls can be interleaved freely.
 
+Weights are addressed the same way: after changing parameters (a state-dict load, `fold_layerscale()`, `pack()`), build
+a new GraphedForward.
+
 The returned tensors are the graph's static output buffers: valid until the next call with the same input shape —
 consume (or clone) them before that, on the stream the call was made on.
 """
