@@ -67,7 +67,7 @@ def make_gallery_shard(rows: int, seed: int, dev) -> torch.Tensor:
 def cpu_baseline(ext_state, arch, head_mods, images_cpu, gallery_sample_cpu, n_total, k):
     """Same op sequence on the host: backbone (PyTorch CPU fp32) + oracle SALAD / kNN / head.
     Bounded sample: `images_cpu` (a few images) and a slice of the gallery, scaled to n_total."""
-    from oracle import heads as oheads, knn as oknn, salad as osalad
+    from oracle import heads as oheads, salad as osalad
     from vpr_amd.modules import DinoV2Salad
     threads = min(os.cpu_count(), 16)          # the GPU box gives one GPU's job a 16-core share
     torch.set_num_threads(threads)
@@ -141,7 +141,6 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a) -> dict:
     """Roofline rows of the other hand-written stages (BASELINE configs 2, 4, 5), each timed on its own after the timed
     region: algorithmic FLOPs / bytes over the average device time of the whole entry point."""
     from vpr_amd import _lib, ops
-    from vpr_amd.gallery import GalleryShard
     from vpr_amd.retrieval import GraphedRetrieval, ShardedGallery
     rows = {}
     B, C = images.shape[0], ext.backbone.embed_dim

@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  MUST precede loading libvpr_amd.so: the library has to bind to the HIP
               # runtime PyTorch ships (torch/lib/libamdhip64.so), not to a second copy from /opt/rocm —
               # two runtimes in one process make every launch fail with hipErrorNoDevice.
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

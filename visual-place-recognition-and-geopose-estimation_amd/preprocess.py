@@ -15,7 +15,7 @@ from __future__ import annotations
 import ctypes
 import math
 from functools import lru_cache
-from typing import Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 import torch
