@@ -62,3 +62,17 @@ def test_loader_reports_a_broken_file(tmp_path):
     with pytest.raises(Exception):
         for _ in ImageBatchLoader(str(tmp_path), names, 2, "cpu", workers=2):
             pass
+
+
+def test_loader_arrow_export_falls_back_for_multi_block_images(tmp_path):
+    """Images above PIL's 16 MB block size are stored in several blocks and have no zero-copy Arrow view: the Arrow
+    export path falls back to the raw export for those files (same bytes)."""
+    from vpr_amd.loader import ImageBatchLoader, _arrow_export_works
+    if not _arrow_export_works():
+        pytest.skip("pyarrow / Pillow Arrow export not available here")
+    rng = np.random.default_rng(2)
+    big = rng.integers(0, 256, (2400, 2000, 3), dtype=np.uint8)          # 19.2 MB as RGBX: two blocks
+    Image.fromarray(big).save(os.path.join(tmp_path, "big0.png"))
+    Image.fromarray(big[::-1].copy()).save(os.path.join(tmp_path, "big1.png"))
+    out = list(ImageBatchLoader(str(tmp_path), ["big0.png", "big1.png"], 2, "cpu", workers=2, export="arrow"))
+    assert len(out) == 1 and np.array_equal(out[0][2][0].numpy(), big) and np.array_equal(out[0][2][1].numpy(), big[::-1])

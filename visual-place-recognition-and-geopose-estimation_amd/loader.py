@@ -60,7 +60,14 @@ def _decode_into(path: str, slot: np.ndarray) -> None:
         rgb = im if im.mode == "RGB" else im.convert("RGB")                 # convert() of an RGB image is a plain copy
         if slot.shape[-1] == 4:
             rgb.load()
-            arr = _pa.array(rgb).values.to_numpy(zero_copy_only=True).reshape(rgb.size[1], rgb.size[0], 4)
+            try:
+                arr = _pa.array(rgb).values.to_numpy(zero_copy_only=True).reshape(rgb.size[1], rgb.size[0], 4)
+            except ValueError:                 # images above PIL's 16 MB block size live in several blocks: no zero-copy view
+                arr = np.asarray(rgb)
+                if arr.shape != slot.shape[:2] + (3,):
+                    raise RuntimeError(f"{path}: decoded to {arr.shape}, its header promised {slot.shape[:2] + (3,)}")
+                np.copyto(slot[..., :3], arr)  # the X byte of the slot is never read on the device
+                return
         else:
             arr = np.asarray(rgb)
         if arr.shape != slot.shape:
