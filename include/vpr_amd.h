@@ -6,10 +6,16 @@
  * its own; its seam is the nn.Module.forward contract of the validation scripts.  Each entry
  * point below names the reference interface (file:line, relative to the reference root) whose
  * device-side arithmetic it replaces.  All pointers are DEVICE pointers unless stated, all
- * functions are asynchronous on `stream` (a hipStream_t passed as void*), allocate nothing,
- * keep no global state (safe under hipGraph capture) and never throw: they return a
- * vpr_status (0 = ok, negative = error).  Workspace is caller-provided; size it with the
- * matching *_workspace_bytes() call.
+ * functions are asynchronous on `stream` (a hipStream_t passed as void*), allocate nothing
+ * (safe under hipGraph capture) and never throw: they return a vpr_status (0 = ok, negative =
+ * error).  Workspace is caller-provided; size it with the matching *_workspace_bytes() call.
+ * State the library keeps between calls — all of it, none of it data-dependent:
+ *   (1) per DEVICE (keyed by hipGetDevice() at every launch): which kernels have received their
+ *       > 64 KB dynamic-LDS opt-in (hipFuncSetAttribute is a per-device setting) and the cached
+ *       CU count.  A process may drive any number of GPUs, from any threads;
+ *   (2) per PROCESS: the A/B tuning switches (VPR_KNN_VARIANT, ...), read from the environment
+ *       ONCE when the library is loaded — a later setenv() changes nothing — and settable only
+ *       through vpr_tuning_set() (benchmark scripts and tests; every value gives identical results).
  *
  * dtype conventions: "bf16" = uint16_t holding the upper 16 bits of an IEEE fp32
  * (round-to-nearest-even); "f32" = float.
@@ -38,6 +44,14 @@ typedef enum vpr_status {
 const char* vpr_status_string(int status);
 /* ABI version of the loaded library (== VPR_AMD_ABI_VERSION it was built with). */
 int vpr_abi_version(void);
+/* Tuning switches (process-wide A/B knobs; names = the VPR_* environment variables read at load: VPR_KNN_VARIANT,
+ * VPR_KNN_GEMM_MIN_B, VPR_KNN_GEMM_KSPLIT, VPR_KNN_FP8_GEMM256, VPR_GEMM_NT_STAGES, VPR_GEMM_GROUP_VARIANT,
+ * VPR_ATTN_VARIANT, VPR_LN_ROWS, VPR_POSE_KS, VPR_SKINNY_NW, VPR_SKINNY_MBW, VPR_SALAD_VARIANT, VPR_POSE_VARIANT,
+ * VPR_LNHEAD_VARIANT).  vpr_tuning_set: unset != 0 restores "not set".  vpr_tuning_get: 0 and *value, 1 if the
+ * switch is not set, VPR_ERR_INVALID_ARG for an unknown name.  Not for production code paths: no call may be in
+ * flight on another thread while a switch changes. */
+int vpr_tuning_set(const char* name, int value, int unset);
+int vpr_tuning_get(const char* name, int* value);
 
 /* ------------------------------------------------------------------------------------------
  * SALAD optimal-transport aggregation.

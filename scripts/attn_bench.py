@@ -1,6 +1,6 @@
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 B, T, H = 64, 257, 16
 qkv = torch.randn(B, T, 3 * H * 64, device=dev, dtype=torch.bfloat16)
@@ -20,6 +20,6 @@ def timeit(fn, n=30):
 for r in range(3):
     line = f"sdpa {timeit(sdpa):.1f} us"
     for v in (0, 13, 14, 12):      # 0 = default; 13 staging only, 14 + QK^T, 12 + softmax (ablations, wrong results)
-        os.environ["VPR_ATTN_VARIANT"] = str(v)
+        _lib.tuning_set("VPR_ATTN_VARIANT", int(v))
         line += f"   v{v} {timeit(mine):.1f} us"
     print(line)

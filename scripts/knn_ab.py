@@ -2,7 +2,7 @@
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=100000)
@@ -23,7 +23,7 @@ variants = [int(v) for v in a.variants.split(",")]
 times = {v: [] for v in variants}
 for r in range(a.rounds + 1):
     for v in variants:
-        os.environ["VPR_KNN_VARIANT"] = str(v)
+        _lib.tuning_set("VPR_KNN_VARIANT", int(v))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ops.knn_scores(q, gal, ws)
         e0.record(); ops.knn_scores(q, gal, ws); ops.knn_scores(q, gal, ws); e1.record()

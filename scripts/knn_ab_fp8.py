@@ -1,7 +1,7 @@
 """A/B of knn_scores_kernel variants on an e4m3 gallery (whole vpr_knn_topk_fp8 call), one process, interleaved."""
 import argparse, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--N", type=int, default=1000000)
 ap.add_argument("--variants", default="0,3")
@@ -22,7 +22,7 @@ times = {v: [] for v in variants}
 ref = None
 for r in range(a.rounds + 1):
     for v in variants:
-        os.environ["VPR_KNN_VARIANT"] = str(v)
+        _lib.tuning_set("VPR_KNN_VARIANT", int(v))
         out = ops.knn_topk_fp8(q8, qs, g8, gs, 10, 0, ws)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); ops.knn_topk_fp8(q8, qs, g8, gs, 10, 0, ws); ops.knn_topk_fp8(q8, qs, g8, gs, 10, 0, ws); e1.record()

@@ -4,7 +4,7 @@ the epilogue (VERDICT r1 #6b).  Events around the score stage of the real call (
   VPR_AMD_LIBRARY=$PWD/visual-place-recognition-and-geopose-estimation_amd/libvpr_amd_ablation.so python scripts/knn_ablation.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 D, k, B = 8448, 10, 64
 g = torch.Generator(device=dev).manual_seed(0)
@@ -44,9 +44,9 @@ for (N, fp8) in [(100_000, False), (500_000, False), (125_000, True), (1_000_000
     gb = N * D * (1 if fp8 else 2) / 1e3
     for rep in range(2):
         for variant, name in ((0, "shipped"), (14, "no score stores")):
-            os.environ["VPR_KNN_VARIANT"] = str(variant)
+            _lib.tuning_set("VPR_KNN_VARIANT", int(variant))
             t = score_us(call)
             line += f"  {name} {t:7.1f} us ({gb / t / 1e3:.2f} TB/s)"
-    os.environ["VPR_KNN_VARIANT"] = "0"
+    _lib.tuning_set("VPR_KNN_VARIANT", 0)
     print(line, flush=True)
     del G, ws

@@ -2,7 +2,7 @@
 vs the MFMA GEMM path (VPR_KNN_GEMM_MIN_B picks the crossover)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 D = 8448
 g = torch.Generator(device=dev).manual_seed(0)
@@ -24,9 +24,9 @@ for (B, N) in [(128, 50000), (192, 33333), (256, 25000), (512, 12500), (256, 250
     ws = ops.knn_workspace(B, N, D, 10, dev)
     line = f"B={B:4d} N={N:6d}:"
     for thr, stages, g256 in ((100000, "2", "1"), (1, "2", "0"), (1, "3", "0"), (1, "2", "1")):
-        os.environ["VPR_KNN_GEMM_MIN_B"] = str(thr)
-        os.environ["VPR_GEMM_NT_STAGES"] = stages
-        os.environ["VPR_KNN_FP8_GEMM256"] = g256
+        _lib.tuning_set("VPR_KNN_GEMM_MIN_B", int(thr))
+        _lib.tuning_set("VPR_GEMM_NT_STAGES", int(stages))
+        _lib.tuning_set("VPR_KNN_FP8_GEMM256", int(g256))
         t = timeit(lambda: ops.knn_scores(q, gal, ws))
         line += f"  {'stream' if thr > 1 else ('gemm/' + stages + '-stage' if g256 == '0' else 'auto(256-tile when it fills)')} {t:7.1f} us"
     print(line, flush=True)

@@ -1,7 +1,7 @@
 """fp8 score stage for > 64 queries: streaming kernel (one gallery pass per 64 queries) vs block-scaled fp8 GEMM."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 D = 8448
 g = torch.Generator(device=dev).manual_seed(0)
@@ -24,7 +24,7 @@ for (B, N) in [(128, 500000), (256, 250000), (512, 125000)]:
     ws = ops.knn_workspace(B, N, D, 10, dev)
     line = f"B={B:4d} N={N:7d}:"
     for thr in (100000, 65):
-        os.environ["VPR_KNN_GEMM_MIN_B"] = str(thr)
+        _lib.tuning_set("VPR_KNN_GEMM_MIN_B", int(thr))
         t = timeit(lambda: ops.knn_topk_fp8(q, qs, gal, gs, 10, 0, ws))
         line += f"  {'stream' if thr > 65 else 'gemm  '} {t:8.1f} us"
     print(line + f"   ({2*B*N*D/1e12:.2f} TFLOP)", flush=True)

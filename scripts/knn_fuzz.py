@@ -5,7 +5,7 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import knn as oknn
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 import test_knn_gpu as T
 dev = torch.device("cuda:0")
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 1000), (int(sys.argv[2]) if len(sys.argv) > 2 else 6)
@@ -13,7 +13,7 @@ bad = total = 0
 for seed in range(first, first + count):
     for fp8 in (False, True):
         for variant in ("0", "7"):
-            os.environ["VPR_KNN_VARIANT"] = variant
+            _lib.tuning_set("VPR_KNN_VARIANT", int(variant))
             for (B, N, D, k, sd, base) in T._random_shapes(seed, 25, fp8):
                 if fp8:
                     q, qs = T._fp8_rows(B, D, sd); g, gs = T._fp8_rows(N, D, sd + 1)

@@ -45,7 +45,7 @@ for (B, N) in [(256, 25000), (512, 12500), (512, 6378), (256, 50000), (512, 2500
         line = f"B={B:4d} N={N:6d} {'e4m3' if fp8 else 'bf16'}:"
         res = []
         for ks in ("0", "1"):
-            os.environ["VPR_KNN_GEMM_KSPLIT"] = ks
+            _lib.tuning_set("VPR_KNN_GEMM_KSPLIT", int(ks))
             v, i = call()
             res.append((v.clone(), i.clone()))
             name = _lib.lib().vpr_knn_scores_kernel_name(int(fp8), B, N).decode().replace("vpr::", "")

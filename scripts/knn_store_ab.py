@@ -3,7 +3,7 @@ stores, 6 whole row segments through LDS, 7 the same with nt stores): score-stag
 the real call) and identical answers."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 D, k, B = 8448, 10, 64
 g = torch.Generator(device=dev).manual_seed(0)
@@ -44,7 +44,7 @@ for (N, fp8) in [(100_000, False), (500_000, False), (125_000, True), (1_000_000
     ref = None
     for rep in range(2):
         for variant in VARIANTS:
-            os.environ["VPR_KNN_VARIANT"] = str(variant)
+            _lib.tuning_set("VPR_KNN_VARIANT", int(variant))
             ws.zero_()
             t, (v, i) = score_us(call)
             S = ops.knn_scores_view(ws, B, N, D, k).clone() if N <= 125_000 else None
@@ -52,6 +52,6 @@ for (N, fp8) in [(100_000, False), (500_000, False), (125_000, True), (1_000_000
                 ref = (v.clone(), i.clone(), S)
             same = torch.equal(v, ref[0]) and torch.equal(i, ref[1]) and (S is None or torch.equal(S, ref[2]))
             line += f"  v{variant} {t:7.1f} us ({gb / t / 1e3:.2f} TB/s){'' if same else ' DIFF!'}"
-    os.environ["VPR_KNN_VARIANT"] = "0"
+    _lib.tuning_set("VPR_KNN_VARIANT", 0)
     print(line, flush=True)
     del G, ws

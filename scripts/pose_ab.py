@@ -1,7 +1,7 @@
 """A/B of the pose head's split-K factor (VPR_POSE_KS) and timing of the Swin pooler head, one process, interleaved."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vpr_amd import ops
+from vpr_amd import _lib, ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 B, D, H = 64, 8448, 1024
@@ -22,8 +22,8 @@ ks_list = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,11,16,22,24
 res = {k: [] for k in ks_list}
 for r in range(6):
     for k in ks_list:
-        if k: os.environ["VPR_POSE_KS"] = str(k)
-        else: os.environ.pop("VPR_POSE_KS", None)
+        if k: _lib.tuning_set("VPR_POSE_KS", int(k))
+        else: _lib.tuning_set("VPR_POSE_KS", None)
         t = timeit(lambda: ops.pose_head(x, W1, b1, W2, b2, 2))
         res[k].append(t)
 for k in ks_list:

@@ -193,7 +193,7 @@ def test_quantize_fp8_matches_torch(dev):
 
 
 @pytest.mark.parametrize("B", [150, 256, 300, 512])
-def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch, B):
+def test_knn_fp8_gemm_path_scores_match_stream_path(dev, tune, B):
     """More than 64 queries: the block-scaled fp8 MFMA GEMMs — the 128 x 128-tile kernel (v_mfma_scale_f32_32x32x64_f8f6f4)
     when a 256-row query tile would be less than 3/4 full, else the 256 x 256-tile gemm256_kernel<true>
     (v_mfma_scale_f32_16x16x128_f8f6f4, LDS-DMA in flight across barriers) — must produce the score matrix the streaming kernel produces (same exact fp8 products,
@@ -207,7 +207,7 @@ def test_knn_fp8_gemm_path_scores_match_stream_path(dev, monkeypatch, B):
     q, qs, g, gs = q.to(dev), qs.to(dev), g.to(dev), gs.to(dev)
     outs = []
     for thr in ("100000", "65"):
-        monkeypatch.setenv("VPR_KNN_GEMM_MIN_B", thr)
+        tune("VPR_KNN_GEMM_MIN_B", thr)
         ws = ops.knn_workspace(B, N, D, k, dev)
         ws.zero_()
         v, i = ops.knn_topk_fp8(q, qs, g, gs, k, 0, ws)
@@ -373,7 +373,7 @@ def test_knn_two_stage_call_equals_one_call(dev, B, N, fp8):
 
 
 @pytest.mark.parametrize("fp8", [False, True])
-def test_knn_gemm_split_k_equals_unsplit(dev, monkeypatch, fp8):
+def test_knn_gemm_split_k_equals_unsplit(dev, tune, fp8):
     """Gathered batch against a shard with fewer than 256 score tiles: the 256 x 256-tile GEMM splits K into slabs the
     level-0 select adds.  Same final answer as the unsplit routes (exact rescoring), and the summed score matrix agrees
     with the unsplit one to f32 summation-order noise."""
@@ -393,7 +393,7 @@ def test_knn_gemm_split_k_equals_unsplit(dev, monkeypatch, fp8):
         call = lambda ws: ops.knn_topk(Q, G, k, 0, ws)
     outs = []
     for ks in ("0", "1"):
-        monkeypatch.setenv("VPR_KNN_GEMM_KSPLIT", ks)
+        tune("VPR_KNN_GEMM_KSPLIT", ks)
         ws = ops.knn_workspace(B, N, D, k, dev)
         ws.zero_()
         v, i = call(ws)
@@ -514,7 +514,7 @@ def test_knn_default_bound_certifies_normalised_descriptors(dev):
 @pytest.mark.parametrize("B,N,D,fp8", [(64, 20000, 8448, False), (64, 20000, 8448, True), (7, 1003, 256, False),
                                        (64, 131, 128, True), (33, 5, 64, False), (50, 150_001, 128, False)])
 @pytest.mark.parametrize("variant", ["6", "7"])
-def test_knn_staged_score_stores_equal_direct(dev, monkeypatch, B, N, D, fp8, variant):
+def test_knn_staged_score_stores_equal_direct(dev, tune, B, N, D, fp8, variant):
     """The score kernel of multi-tile shards (N > 131k rows) writes each tile's scores as whole row segments staged
     through LDS (VPR_KNN_VARIANT 6 / 7 force that path, plain / nt stores, at any size): the score matrix and the answer
     are bit-identical to the direct-store kernel's (variant 5), ragged tiles, batches and row counts included."""
@@ -528,10 +528,10 @@ def test_knn_staged_score_stores_equal_direct(dev, monkeypatch, B, N, D, fp8, va
     else:
         args = (_unit_rows(B, D, 91).to(dev), _unit_rows(N, D, 92).to(dev), k, 0)
         fn = ops.knn_topk
-    monkeypatch.setenv("VPR_KNN_GEMM_MIN_B", "100000")
+    tune("VPR_KNN_GEMM_MIN_B", "100000")
     outs = []
     for var in ("5", variant):
-        monkeypatch.setenv("VPR_KNN_VARIANT", var)
+        tune("VPR_KNN_VARIANT", var)
         ws = ops.knn_workspace(B, N, D, k, dev)
         ws.zero_()
         v, i = fn(*args, ws)

@@ -99,3 +99,35 @@ def test_lds_swizzle_is_conflict_free():
     # the staging side writes physical slot (row, p) with logical chunk p ^ swz(row): a bijection per row
     for row in range(16):
         assert sorted((p ^ ((row >> 1) & 7)) for p in range(8)) == list(range(8))
+
+
+def test_tuning_switches_are_read_once_at_load(lib, monkeypatch):
+    """include/vpr_amd.h, "State the library keeps": the VPR_* switches are read from the environment when the library
+    is loaded; a later setenv() has no effect, vpr_tuning_set() is the only way to change one, unknown names are refused."""
+    from vpr_amd import _lib
+    before = _lib.tuning_get("VPR_KNN_VARIANT")
+    monkeypatch.setenv("VPR_KNN_VARIANT", "6")
+    monkeypatch.setenv("VPR_POSE_KS", "9")
+    assert _lib.tuning_get("VPR_KNN_VARIANT") == before               # the environment is not consulted again
+    assert lib.vpr_knn_scores_kernel_name(0, 64, 100000) == b"vpr::knn_scores_kernel<false, 208, 2, 4>" or before not in (None, 0)
+    with _lib.tuning(VPR_KNN_VARIANT=1):
+        assert _lib.tuning_get("VPR_KNN_VARIANT") == 1
+        assert lib.vpr_knn_scores_kernel_name(0, 64, 100000) == b"vpr::knn_scores_kernel<false, 208, 2, 0>"
+    assert _lib.tuning_get("VPR_KNN_VARIANT") == before
+    v = ctypes.c_int(0)
+    assert lib.vpr_tuning_get(b"VPR_NOT_A_SWITCH", ctypes.byref(v)) == -1
+    assert lib.vpr_tuning_set(b"VPR_NOT_A_SWITCH", 1, 0) == -1
+    assert lib.vpr_tuning_set(None, 1, 0) == -1
+
+
+def test_tuning_switches_come_from_the_environment_of_the_loading_process():
+    """A fresh process with VPR_KNN_VARIANT=1 in its environment loads a library that reports 1 (and picks that kernel)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import vpr_amd; from vpr_amd import _lib; "
+            "print(_lib.tuning_get('VPR_KNN_VARIANT'), _lib.tuning_get('VPR_POSE_KS'), "
+            "_lib.lib().vpr_knn_scores_kernel_name(0, 64, 100000).decode())" % ROOT)
+    env = dict(os.environ, VPR_KNN_VARIANT="1")
+    env.pop("VPR_POSE_KS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == "1" and out[1] == "None" and "208, 2, 0" in " ".join(out[2:])

@@ -29,6 +29,8 @@ class SaladWeightsC(Structure):
 PROTOTYPES = {
     "vpr_status_string": (c_char_p, [c_int]),
     "vpr_abi_version": (c_int, []),
+    "vpr_tuning_set": (c_int, [c_char_p, c_int, c_int]),
+    "vpr_tuning_get": (c_int, [c_char_p, POINTER(c_int)]),
     "vpr_salad_workspace_bytes": (c_size_t, [c_int] * 7),
     "vpr_salad_aggregate": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(SaladWeightsC), c_float,
                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
@@ -122,6 +124,40 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError("libvpr_amd.so ABI version mismatch; rebuild the library")
         _LIB = handle
     return _LIB
+
+
+def tuning_set(name: str, value=None) -> None:
+    """Set (or, with value None, unset) one of the library's A/B switches.  The library reads the VPR_* environment
+    variables once at load; afterwards this call is the only way to change them (scripts/, tests)."""
+    st = lib().vpr_tuning_set(name.encode(), 0 if value is None else int(value), int(value is None))
+    check(st, f"vpr_tuning_set({name})")
+
+
+def tuning_get(name: str):
+    v = c_int(0)
+    st = lib().vpr_tuning_get(name.encode(), ctypes.byref(v))
+    if st == 1:
+        return None
+    check(st, f"vpr_tuning_get({name})")
+    return v.value
+
+
+class tuning:
+    """Context manager: `with _lib.tuning(VPR_KNN_VARIANT=6): ...` sets the switches and restores the old values."""
+
+    def __init__(self, **switches):
+        self.switches, self.old = switches, {}
+
+    def __enter__(self):
+        for k, v in self.switches.items():
+            self.old[k] = tuning_get(k)
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tuning_set(k, v)
+        return False
 
 
 def check(status: int, what: str) -> None:

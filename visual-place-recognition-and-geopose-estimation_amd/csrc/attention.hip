@@ -262,19 +262,13 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
   if (!qkv || !out || B <= 0 || T <= 0 || H <= 0 || Tp < 0 || Tp > T || tail_row0 < 0) return VPR_ERR_INVALID_ARG;
   if (head_dim != AT_D || T > AT_KP || (long long)B * H > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) return VPR_ERR_UNSUPPORTED;
-  const char* venv = getenv("VPR_ATTN_VARIANT");      // A/B switch; 0 = default
-  const int variant = venv ? atoi(venv) : 0;
+  const int variant = tune_or(TUNE_ATTN_VARIANT, 0);      // A/B switch; 0 = default
   const float c = scale * 1.4426950408889634f;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define VPR_ATTN_LAUNCH(NW, PIPE)                                                                        \
   do {                                                                                                   \
-    static bool attr = false;                                                                            \
-    if (!attr) {                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<NW, PIPE>),                 \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_LDS) != hipSuccess)    \
-        return VPR_ERR_LAUNCH;                                                                           \
-      attr = true;                                                                                       \
-    }                                                                                                    \
+    static PerDeviceFlag attr = {};                                                                      \
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<NW, PIPE>), AT_LDS, attr)); \
     VPR_TRY_LAUNCH(launch_kernel(attention_kernel<NW, PIPE>, dim3((unsigned)(B * H)), dim3(NW * 64), AT_LDS, st, \
                                  qkv, out, T, Tp, tail_row0, H, c));                                                    \
   } while (0)

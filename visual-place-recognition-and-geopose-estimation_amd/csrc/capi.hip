@@ -1,4 +1,6 @@
 // capi.hip — C-ABI odds and ends of libvpr_amd.so (see include/vpr_amd.h for the contract).
+#include <stdlib.h>
+#include <string.h>
 #include "vpr_common.h"
 #include "vpr_internal.h"
 
@@ -22,9 +24,60 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   }
 }
 
+// ---- tuning switches: environment read once at load --------------------------------------------------------------
+static const char* const kTuneNames[TUNE_COUNT] = {
+    "VPR_KNN_VARIANT", "VPR_KNN_GEMM_MIN_B", "VPR_KNN_GEMM_KSPLIT", "VPR_KNN_FP8_GEMM256", "VPR_GEMM_NT_STAGES",
+    "VPR_GEMM_GROUP_VARIANT", "VPR_ATTN_VARIANT", "VPR_LN_ROWS", "VPR_POSE_KS", "VPR_SKINNY_NW", "VPR_SKINNY_MBW",
+    "VPR_SALAD_VARIANT", "VPR_POSE_VARIANT", "VPR_LNHEAD_VARIANT"};
+struct TuneTable {
+  int v[TUNE_COUNT];
+  TuneTable() {
+    for (int i = 0; i < TUNE_COUNT; ++i) {
+      const char* e = getenv(kTuneNames[i]);
+      v[i] = (e && *e) ? atoi(e) : TUNE_UNSET;
+    }
+  }
+};
+static TuneTable g_tune;           // constructed by the dynamic loader, before any entry point can run
+int tune(TuneOpt o) { return g_tune.v[o]; }
+
+// ---- per-device CU count --------------------------------------------------------------------------------------------
+int device_cu_count() {
+  static int cached[VPR_MAX_DEVICES] = {};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VPR_MAX_DEVICES) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 }  // namespace vpr
 
 using namespace vpr;
+
+extern "C" int vpr_tuning_set(const char* name, int value, int unset) {
+  if (!name) return VPR_ERR_INVALID_ARG;
+  for (int i = 0; i < TUNE_COUNT; ++i)
+    if (strcmp(name, kTuneNames[i]) == 0) {
+      g_tune.v[i] = unset ? TUNE_UNSET : value;
+      return VPR_OK;
+    }
+  return VPR_ERR_INVALID_ARG;
+}
+
+extern "C" int vpr_tuning_get(const char* name, int* value) {
+  if (!name || !value) return VPR_ERR_INVALID_ARG;
+  for (int i = 0; i < TUNE_COUNT; ++i)
+    if (strcmp(name, kTuneNames[i]) == 0) {
+      if (g_tune.v[i] == TUNE_UNSET) return 1;      // 1 = known switch, not set
+      *value = g_tune.v[i];
+      return VPR_OK;
+    }
+  return VPR_ERR_INVALID_ARG;
+}
 
 extern "C" const char* vpr_status_string(int status) {
   switch (status) {

@@ -323,13 +323,8 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   g.a_scale = g.w_scale = nullptr;
   const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   if (ksplit > 1 && (g.bias != nullptr || g.relu || g.K / 64 < 2 * ksplit)) return VPR_ERR_UNSUPPORTED;   // slabs are linear partial sums
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G2_LDS) != hipSuccess)
-      return VPR_ERR_LAUNCH;
-    attr = true;
-  }
+  static PerDeviceFlag attr = {};
+  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<false>), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
   return VPR_OK;
 }
@@ -345,13 +340,8 @@ int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const ui
     return VPR_ERR_UNSUPPORTED;
   GemmProblem g{reinterpret_cast<const uint16_t*>(A), lda, 0, 0, reinterpret_cast<const uint16_t*>(W), ldw, nullptr, 0,
                 C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale, ksplit, slab_stride};
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)G2_LDS) != hipSuccess)
-      return VPR_ERR_LAUNCH;
-    attr = true;
-  }
+  static PerDeviceFlag attr = {};
+  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<true>), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<true>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
   return VPR_OK;
 }

@@ -313,16 +313,10 @@ int launch_gemm_nt(const uint16_t* A, int lda, int a_group_rows, long long a_gro
     g.tiles_n = (N + 127) / 128;
     // A/B switch: 3 = three-deep ring (96 KB: one workgroup per CU).  Measured on the kNN score tile, 2 vs 3
     // stages: 128 x 50k 217 / 291 us, 512 x 12.5k 141 / 205 us — two workgroups per CU beat the deeper ring.
-    const char* senv = getenv("VPR_GEMM_NT_STAGES");
-    if (senv && atoi(senv) == 3) {
+    if (tune_or(TUNE_GEMM_NT_STAGES, 2) == 3) {
       constexpr size_t lds3 = 3 * (128 + 128) * TILE_ROW_BYTES;
-      static bool attr = false;
-      if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<128, 2, 2, 3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-          return VPR_ERR_LAUNCH;
-        attr = true;
-      }
+      static PerDeviceFlag attr = {};
+      VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<128, 2, 2, 3>), lds3, attr));
       VPR_TRY_LAUNCH(launch_kernel((gemm_nt_kernel<128, 2, 2, 3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds3, stream, g));
       return VPR_OK;
     }
@@ -357,8 +351,7 @@ int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream
   // tiles (72 KB of LDS: still two workgroups per CU, so the ~390 workgroups stay one resident round; a 3-deep
   // ring on 128 x 128 tiles is 96 KB = one workgroup per CU and 258 workgroups then need a second round:
   // measured 101.6 vs 88.9 us for the whole SALAD stage).
-  const char* senv = getenv("VPR_GEMM_GROUP_VARIANT");     // A/B switch
-  const int variant = senv ? atoi(senv) : 1;              // 0 = 128 x 128 tiles, 2-deep ring (89.9 us); 1 = default (84.4 us)
+  const int variant = tune_or(TUNE_GEMM_GROUP_VARIANT, 1);   // A/B switch: 0 = 128 x 128 tiles, 2-deep ring (89.9 us); 1 = default (84.4 us)
   if (variant == 1) {
     total = 0;
     for (int i = 0; i < count; ++i) {
@@ -367,13 +360,8 @@ int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream
     }
     for (int i = count; i < GEMM_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     constexpr size_t lds3 = 3 * (128 + 64) * TILE_ROW_BYTES;
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_group_kernel<64, 4, 1, 3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-        return VPR_ERR_LAUNCH;
-      attr = true;
-    }
+    static PerDeviceFlag attr = {};
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_group_kernel<64, 4, 1, 3>), lds3, attr));
     VPR_TRY_LAUNCH(launch_kernel((gemm_nt_group_kernel<64, 4, 1, 3>), dim3(total), dim3(256), lds3, stream, grp));
     return VPR_OK;
   }

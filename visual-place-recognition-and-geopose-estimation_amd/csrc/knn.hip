@@ -980,17 +980,7 @@ static bool knn_plan(int B, int N, int D, int k, KnnPlan* p) {
   return true;
 }
 
-static int g_num_cu = 0;
-static int num_cus() {
-  if (g_num_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    g_num_cu = n;
-  }
-  return g_num_cu;
-}
+static int num_cus() { return device_cu_count(); }      // per device (vpr_internal.h)
 
 struct KnnOperands {          // bf16: scales are null; fp8: per-row f32 scales
   const void* q; const void* g; const float* q_scale; const float* g_scale; bool fp8;
@@ -1019,8 +1009,7 @@ static bool knn_multi_tile(int N) {
 // 256-row query tiles pay when at least 3/4 of their rows are real queries (256 gathered queries = 4 GPUs, 512 = 8 GPUs);
 // VPR_KNN_FP8_GEMM256=0 forces the 128 x 128 kernel (A/B).
 static bool knn_query_tile256_pays(int B) {
-  const char* e = getenv("VPR_KNN_FP8_GEMM256");
-  if (e && !atoi(e)) return false;
+  if (tune_or(TUNE_KNN_FP8_GEMM256, 1) == 0) return false;
   const int tiles = (B + 255) / 256;
   return 4 * B >= 3 * tiles * 256;
 }
@@ -1036,8 +1025,7 @@ static int knn_ksplit(const KnnPlan& p, int row_bytes) {
 // used by the score stage, the select stage and vpr_knn_scores_kernel_name.
 enum KnnRoute { ROUTE_STREAM, ROUTE_GEMM128, ROUTE_GEMM256 };
 static KnnRoute knn_route(const KnnPlan& p, bool fp8, int B, int N, int D, bool ksplit_ok, int* nslab) {
-  const char* genv = getenv("VPR_KNN_GEMM_MIN_B");     // A/B switch for the stream / GEMM crossover
-  const int gemm_min_b = genv ? atoi(genv) : 65;
+  const int gemm_min_b = tune_or(TUNE_KNN_GEMM_MIN_B, 65);     // A/B switch for the stream / GEMM crossover
   const int rb = fp8 ? D : D * 2;
   *nslab = 1;
   if (B < gemm_min_b) {                                 // streaming kernel; shards below 106k rows split K over tall tiles
@@ -1048,8 +1036,7 @@ static KnnRoute knn_route(const KnnPlan& p, bool fp8, int B, int N, int D, bool 
   // 256 x 256 tiles, one workgroup per CU: with the K split a 512 x 12.5k problem (98 tiles) runs as 196 workgroups.
   // Without it (stand-alone score entry point, or VPR_KNN_GEMM_KSPLIT=0) bf16 needs >= 256 tiles to beat the 128 x 128
   // kernel's 4x as many workgroups.
-  const char* kenv = getenv("VPR_KNN_GEMM_KSPLIT");
-  int ks = (ksplit_ok && B > KNN_QT && !(kenv && !atoi(kenv))) ? knn_ksplit(p, rb) : 1;
+  int ks = (ksplit_ok && B > KNN_QT && tune_or(TUNE_KNN_GEMM_KSPLIT, 1) != 0) ? knn_ksplit(p, rb) : 1;
   const long long tiles = (long long)((B + 255) / 256) * ((N + 255) / 256);
   if (!fp8 && tiles * ks < 192) return ROUTE_GEMM128;
   *nslab = ks;
@@ -1094,8 +1081,7 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   // Tile height / residency / cache-policy variants (same arithmetic, same results); 0 is the default, the
   // others exist for A/B tuning in one process (VPR_KNN_VARIANT).  The ablation variants of round 1 (11-13: they
   // skip work and return wrong scores) are compiled only with -DVPR_ABLATION.
-  const char* venv = getenv("VPR_KNN_VARIANT");
-  const int variant = venv ? atoi(venv) : 0;
+  const int variant = tune_or(TUNE_KNN_VARIANT, 0);
   int tr = 208, wgpc = 2;                         // default: 13 row blocks, 2 workgroups per CU
   if (variant == 2) { tr = 144; wgpc = 3; }
   // Shards whose workgroups own more than one 208-row tile (N > 106k) take 256-row tiles: 16 row blocks, 2 x 80 KB = the
@@ -1122,13 +1108,9 @@ int knn_scores(const KnnOperands& o, int B, int N, int D, void* ws, size_t ws_by
   const dim3 grid(nwg, p.Bpad / KNN_QT, ksplit);
 #define VPR_KNN_LAUNCH(F8, TR, W, A)                                                                   \
   do {                                                                                                 \
-    static bool attr = false;                                                                          \
-    if (!attr && lds > 65536) {                                                                        \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scores_kernel<F8, TR, W, A>),          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)     \
-        return VPR_ERR_LAUNCH;                                                                         \
-      attr = true;                                                                                     \
-    }                                                                                                  \
+    static PerDeviceFlag attr = {};                                                                    \
+    if (lds > 65536)                                                                                   \
+      VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(knn_scores_kernel<F8, TR, W, A>), lds, attr)); \
     VPR_TRY_LAUNCH(launch_kernel(knn_scores_kernel<F8, TR, W, A>, grid, dim3(256), lds, stream, o.q, o.g, \
                                  o.q_scale, o.g_scale, S, B, N, rb, p.ldS));                           \
   } while (0)
@@ -1300,8 +1282,7 @@ extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N) {
   const KnnRoute route = knn_route(p, is_fp8 != 0, B, N, 8448, true, &nslab);
   if (route == ROUTE_GEMM256) return is_fp8 ? "vpr::gemm256_kernel<true>" : "vpr::gemm256_kernel<false>";
   if (route == ROUTE_GEMM128) return is_fp8 ? "vpr::gemm_nt_fp8_kernel" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
-  const char* venv = getenv("VPR_KNN_VARIANT");
-  const int variant = venv ? atoi(venv) : 0;
+  const int variant = tune_or(TUNE_KNN_VARIANT, 0);
   const bool tall = variant == 3 || (variant == 0 && knn_tall_tiles(N));
   if (variant == 0 && knn_multi_tile(N))
     return is_fp8 ? "vpr::knn_scores_kernel<true, 256, 2, 52>" : "vpr::knn_scores_kernel<false, 256, 2, 52>";

@@ -103,8 +103,8 @@ template <typename ParamT>
 static int launch_ln(const uint16_t* x, const uint16_t* res, uint16_t* sum_out, const float* pb, const ParamT* g, const ParamT* b,
                      float eps, uint16_t* y, long long M, int C, hipStream_t stream) {
   const int nch = (C / 8 + 63) / 64;
-  const char* venv = getenv("VPR_LN_ROWS");              // A/B switch: rows per wave.  Measured in bench.py on one box:
-  const int rw = venv ? atoi(venv) : 1;                  // 2 rows 11.80/11.80 ms per step, 1 row 11.75/11.72 -> default 1
+  // A/B switch: rows per wave.  Measured in bench.py on one box:
+  const int rw = tune_or(TUNE_LN_ROWS, 1);               // 2 rows 11.80/11.80 ms per step, 1 row 11.75/11.72 -> default 1
 #define VPR_LN_LAUNCH(NCHV, RWV)                                                                                   \
   VPR_TRY_LAUNCH(launch_kernel(layernorm_bf16_kernel<NCHV, ParamT, RWV>, dim3((unsigned)((M + 4 * RWV - 1) / (4 * RWV))), \
                                dim3(256), 0, stream, x, res, sum_out, pb, g, b, eps, y, M, C))

@@ -404,8 +404,8 @@ static int pick_slices_split(int B, int D, int hidden) {
   if (ks > max_ks) ks = max_ks;
   if (ks > 32) ks = 32;
   if (ks < 1) ks = 1;
-  const char* e = getenv("VPR_POSE_KS");          // A/B switch (slices per tile), clamped to what the workspace query allows
-  if (e && atoi(e) >= 1 && atoi(e) <= 64 && atoi(e) <= (D / 32)) ks = atoi(e);
+  const int e = tune_or(TUNE_POSE_KS, 0);         // A/B switch (slices per tile), clamped to what the workspace query allows
+  if (e >= 1 && e <= 64 && e <= (D / 32)) ks = e;
   return ks;
 }
 
@@ -522,13 +522,8 @@ extern "C" int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const 
   float* part = static_cast<float*>(workspace);
   constexpr size_t l1_lds = 4 * 4 * 4 * 64 * 4 * sizeof(float);   // 64 KB
   {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(pose_l1_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)l1_lds) != hipSuccess)
-        return VPR_ERR_LAUNCH;
-      attr = true;
-    }
+    static PerDeviceFlag attr = {};
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(pose_l1_split_kernel), l1_lds, attr));
   }
   VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), l1_lds, stream, x,
                                W1_hi, W1_lo, part, B, D, hidden, sps));

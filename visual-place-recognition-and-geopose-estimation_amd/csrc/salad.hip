@@ -261,13 +261,8 @@ int launch_sinkhorn_aggregate(const float* scores, const float* feats, const flo
                               float* out_f32, uint16_t* out_bf16, hipStream_t stream) {
   if (!scores || !feats || !tokfeat || !out_f32 || B <= 0 || iters < 1) return VPR_ERR_INVALID_ARG;
   if (n != SA_N || m != SA_M || l != SA_L || t != SA_T) return VPR_ERR_UNSUPPORTED;
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINKHORN_LDS) != hipSuccess)
-      return VPR_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static PerDeviceFlag attr = {};   // > 64 KiB of dynamic LDS needs the opt-in once per device
+  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel), SINKHORN_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel, dim3(B), dim3(256), SINKHORN_LDS, stream,
                      scores, feats, tokfeat, dustbin, iters, out_f32, out_bf16));
   return VPR_OK;

@@ -139,14 +139,12 @@ int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw
   if (reinterpret_cast<uintptr_t>(out) & 7) return VPR_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ksteps = K / 32;
-  const char* wenv = getenv("VPR_SKINNY_NW");
   const int nw_auto = ksteps >= 64 ? 16 : (ksteps >= 32 ? 8 : 4);
-  const int nw_env = wenv ? atoi(wenv) : 0;
+  const int nw_env = tune_or(TUNE_SKINNY_NW, 0);
   const int nw = (nw_env == 4 || nw_env == 8 || nw_env == 16) ? nw_env : nw_auto;
   // few column blocks (N <= 2048: at most 128 workgroups): one 16-row block per workgroup so the
   // launch still covers the chip and a workgroup pulls 1/4 of the input rows through its L1
-  const char* menv = getenv("VPR_SKINNY_MBW");                  // A/B switch
-  const int mbw_env = menv ? atoi(menv) : 0;
+  const int mbw_env = tune_or(TUNE_SKINNY_MBW, 0);              // A/B switch
   const int mbw = (mbw_env == 1 || mbw_env == 4) ? mbw_env : ((N + 15) / 16 <= 128 && M > 16 ? 1 : 4);
   const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + 16 * mbw - 1) / (16 * mbw)));
   const bool bf = bias_is_bf16 || !bias;

@@ -55,6 +55,36 @@ inline int launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t
   return VPR_OK;
 }
 
+// ---- process-wide tuning switches (A/B experiments) --------------------------------------------------------------
+// Read from the environment ONCE, when the library is loaded (capi.hip); a later setenv() has no effect on the
+// library.  scripts/ and tests flip them through vpr_tuning_set().  TUNE_UNSET = the variable was absent.
+enum TuneOpt {
+  TUNE_KNN_VARIANT = 0, TUNE_KNN_GEMM_MIN_B, TUNE_KNN_GEMM_KSPLIT, TUNE_KNN_FP8_GEMM256, TUNE_GEMM_NT_STAGES,
+  TUNE_GEMM_GROUP_VARIANT, TUNE_ATTN_VARIANT, TUNE_LN_ROWS, TUNE_POSE_KS, TUNE_SKINNY_NW, TUNE_SKINNY_MBW,
+  TUNE_SALAD_VARIANT, TUNE_POSE_VARIANT, TUNE_LNHEAD_VARIANT, TUNE_COUNT
+};
+constexpr int TUNE_UNSET = -2147483647 - 1;
+int tune(TuneOpt o);
+inline int tune_or(TuneOpt o, int dflt) { const int v = tune(o); return v == TUNE_UNSET ? dflt : v; }
+
+// ---- per-device launch state ---------------------------------------------------------------------------------------
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) and the CU count belong to a DEVICE, not to the process: one
+// flag / one cached value per device ordinal, looked up through hipGetDevice() at every launch (~50 ns).  A process
+// that drives several GPUs (or switches device between calls) gets the opt-in on each of them.
+constexpr int VPR_MAX_DEVICES = 64;
+struct PerDeviceFlag { unsigned char set[VPR_MAX_DEVICES]; };
+inline int optin_dynamic_lds(const void* kernel, size_t bytes, PerDeviceFlag& flag) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VPR_MAX_DEVICES) return VPR_ERR_LAUNCH;
+  if (!flag.set[dev]) {      // two threads racing here both set the attribute: harmless
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+      return VPR_ERR_LAUNCH;
+    flag.set[dev] = 1;
+  }
+  return VPR_OK;
+}
+int device_cu_count();      // capi.hip: multiProcessorCount of the current device, cached per device (256 on MI355X)
+
 #define VPR_TRY_LAUNCH(expr) do { const int vpr_st_ = (expr); if (vpr_st_ != VPR_OK) return vpr_st_; } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
