@@ -286,6 +286,41 @@ def config1_swin_tiny(dev) -> dict:
             "gpu_path": "HIP-graph replay of the forward" if fwd.fallback_reason is None else f"eager ({fwd.fallback_reason})"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>` as a child process group; returns its exit code.  The port is one the kernel just handed out."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    print(f"[bench] no launcher in the environment: spawning {n} rank(s): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def collective_probe(gallery, batch: int, k: int, dev, n: int = 20) -> dict:
+    """The exchange steps of one pipeline step on their own (every rank calls this): all-gather of the bf16 query
+    descriptors, packed all-gather of the per-shard top-k, merge — HIP events on the launch stream, average of n.
+    Also counts the ranks the process group really has (sum of ones over the group)."""
+    from vpr_amd.retrieval import all_gather_topk
+    ones = torch.ones(1, device=dev, dtype=torch.int32)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=gallery.group)
+    q = torch.zeros((batch, D_DESC), dtype=torch.bfloat16, device=dev)
+    v = torch.zeros((batch * gallery.world, k), dtype=torch.float32, device=dev)
+    i = torch.zeros((batch * gallery.world, k), dtype=torch.int32, device=dev)
+
+    def once():
+        gallery.gather_queries(q)
+        vs, is_ = all_gather_topk(v, i, gallery.world, gallery.group)
+        gallery.engine.merge(vs, is_)
+    return {"ranks_seen": int(ones.item()), "collective_ms_per_step": _avg_ms(once, n=n, warm=3),
+            "collectives": "all_gather_into_tensor(queries bf16) + all_gather_into_tensor(top-k packed int32) + vpr_topk_merge"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +352,11 @@ def main():
     ap.add_argument("--fp8-rows", type=int, default=1_000_000, help="gallery rows of the e4m3 kNN row (BASELINE config 5 on one GPU)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.force_dist):
+        # Bare `python bench.py --gpus N` (no launcher): become the launcher.  Nothing in this process has touched the GPU
+        # yet (no HIP call, no torch.cuda.is_available()), so starting N fresh rank processes is safe; their stdout is
+        # ours, i.e. rank 0's JSON line is the one line this command prints.
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -454,16 +494,25 @@ def main():
                     "frac": flops / knn_avg_s / 1e12 / peak, "traffic": None,
                     "kernel_ms": knn_avg_s * 1e3, "algorithmic_flops": flops}
 
+    # Planted-positive Recall@1 THROUGH THE SHARDED PATH (outside the timed region; every rank takes part): rank r plants
+    # its B queries next to rows of ITS OWN shard, so the all-gathered batch has its positives spread over all shards;
+    # every query is searched on every shard, the per-shard top-k are all-gathered and merged, and each rank checks its own
+    # rows of the merged answer against the global index it planted.  The reported value is the mean over all ranks.
+    gp = torch.Generator(device=dev).manual_seed(7 + rank)
+    pos_idx = torch.randint(0, n_shard, (a.batch,), device=dev, generator=gp)
+    qn = torch.nn.functional.normalize(shard[pos_idx].float() + 0.1 * torch.randn(a.batch, D_DESC, device=dev, generator=gp), dim=1)
+    _, ti = gallery.search_local_queries(qn.to(torch.bfloat16), 1)
+    hits = (ti[:, 0].long() == pos_idx + lo).double().sum().reshape(1)
+    if use_dist:
+        dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+    recall1 = float(hits.item()) / (a.batch * world)
+    uncertified = gallery.uncertified_queries()                 # summed over the group when the gallery is sharded (a collective)
+    dist_info = {"process_group": (a.backend if use_dist else None), "collectives_in_step": gallery.collective,
+                 "ranks_seen": world if not use_dist else None, "collective_ms_per_step": None}
+    if gallery.collective:
+        dist_info.update(collective_probe(gallery, a.batch, a.k, dev))
+
     if rank == 0:
-        # planted-positive Recall@1 on this rank's shard (outside the timed region)
-        gp = torch.Generator(device=dev).manual_seed(7)
-        pos_idx = torch.randint(0, n_shard, (a.batch,), device=dev, generator=gp)
-        qn = torch.nn.functional.normalize(shard[pos_idx].float() + 0.1 * torch.randn(a.batch, D_DESC, device=dev, generator=gp), dim=1)
-        if a.knn_dtype == "fp8":
-            _, ti = gallery._local(qn.to(torch.bfloat16), 1)
-        else:
-            _, ti = ops.knn_topk(qn.to(torch.bfloat16), shard, 1, lo)
-        recall1 = float((ti[:, 0].long() == pos_idx + lo).double().mean())
 
         # per-stage device time (one extra step each, outside the timed region)
         def stage_ms(fn, n=3):
@@ -495,9 +544,11 @@ def main():
                        "graph_retrieval": bool(a.graph_retrieval)},
             "roofline": roofline,
             "recall_at_1": recall1,
-            "uncertified_queries": gallery.uncertified_queries(),    # kNN answers the device could not certify exact (0 expected)
+            "recall_path": "search_local_queries: query all-gather -> shard search on every rank -> top-k all-gather -> merge; "
+                           "positives planted in every shard" if gallery.collective else "local search (one shard, no collectives)",
+            "uncertified_queries": uncertified,    # kNN answers the device could not certify exact, all shards (0 expected)
             "stages": stages,
-            "dist": {"process_group": (a.backend if use_dist else None), "collectives_in_step": gallery.collective},
+            "dist": dist_info,
         }
         if world == 1 and not a.no_kernel_rows:
             try:                                                # auxiliary rows never cost the run its headline line

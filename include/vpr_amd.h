@@ -98,6 +98,30 @@ int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_
                               float* out_f32, uint16_t* out_bf16,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same aggregation at the reference's own precision: f32 tokens, f32 weights, f32-accurate arithmetic end to end
+ * (dinov2salad/dinov2salad_validation.py:65-66,80-81 run the extractor in fp32: `.cuda()`, no cast).  Every linear
+ * layer runs on the bf16 matrix pipe with both operands split into three bf16 planes (x = h + m + l exactly) and the six
+ * products above 2^-24 of the leading one kept — exact products, f32 accumulation: an f32 GEMM; hidden activations stay
+ * f32 (no bf16 rounding point).  ~6x the matrix work of vpr_salad_aggregate: a precision mode for parity runs.
+ * patch row r of image b at patch + b*patch_img_stride + r*C (elements: covers [B, n, C] and the patch rows inside a
+ * hub-layout [B, 1+n, C] tensor), cls token of image b at cls + b*cls_stride.  Weights: the shapes of vpr_salad_weights,
+ * all f32.  Same output contract.  Pointers 16-byte aligned, strides % 4 == 0. */
+typedef struct vpr_salad_weights_f32 {
+  const float* w1_sc; const float* b1_sc;
+  const float* w2_s;  const float* b2_s;
+  const float* w2_c;  const float* b2_c;
+  const float* w1_t;  const float* b1_t;
+  const float* w2_t;  const float* b2_t;
+} vpr_salad_weights_f32;
+
+size_t vpr_salad_f32_workspace_bytes(int B, int n, int C, int m, int l, int t, int hidden);
+
+int vpr_salad_aggregate_f32(const float* patch, long long patch_img_stride, const float* cls, long long cls_stride,
+                            int B, int n, int C, const vpr_salad_weights_f32* w, float dustbin,
+                            int m, int l, int t, int hidden, int sinkhorn_iters,
+                            float* out_f32, uint16_t* out_bf16,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Sinkhorn + aggregation stage alone (scores/features already computed) — exposed so tests can
  * pin it against closed-form known answers.
  * scores [B, n, m] f32 (token-major), feats [B, n, l] f32, tokfeat [B, t] f32 (un-normalised). */

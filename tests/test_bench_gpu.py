@@ -63,7 +63,12 @@ def test_bench_force_dist_runs_the_collectives_on_rccl(dev):
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = _json_line(p.stdout)
     assert p.stdout.strip().startswith("{") and len(p.stdout.strip().splitlines()) == 1      # RCCL's banner kept off stdout
-    assert d["dist"] == {"process_group": "nccl", "collectives_in_step": True}
+    # bare `python bench.py --gpus 1 --force-dist` (no launcher in the environment) took the self-spawn path: the
+    # script started its rank under torch.distributed.run before touching the GPU and forwarded rank 0's line
+    assert "spawning 1 rank(s)" in p.stderr
+    assert d["dist"]["process_group"] == "nccl" and d["dist"]["collectives_in_step"] is True
+    assert d["dist"]["ranks_seen"] == 1 and d["dist"]["collective_ms_per_step"] > 0       # RCCL group size, exchange steps alone
+    assert "merge" in d["recall_path"]
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["recall_at_1"] == 1.0 and d["uncertified_queries"] == 0
     # two batches in flight on two streams, each step with its collectives on the one process group
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--no-cpu-baseline",
@@ -113,16 +118,27 @@ def test_bench_two_batches_in_flight(dev):
     assert d["config"]["batches_in_flight"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["recall_at_1"] == 1.0
 
 
-def test_bench_two_ranks_gloo_rehearsal(dev):
+@pytest.mark.parametrize("launcher", ["torchrun", "self-spawn"])
+def test_bench_two_ranks_gloo_rehearsal(dev, launcher):
+    """Two ranks sharing the one GPU over gloo, launched the way the driver does (torch.distributed.run) and bare
+    (`python bench.py --gpus 2`: the script spawns its ranks itself).  Recall@1 is computed THROUGH the sharded path: each
+    rank plants its queries next to rows of its own shard, every query is searched on both shards, the per-shard top-k
+    are all-gathered and merged — 1.0 means the merge picked the right shard's answer for the queries of both ranks."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend",
-           "gloo", "--no-cpu-baseline"] + SMALL
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline"] + SMALL
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = _json_line(p.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2+gallery-shard2"
     assert d["value"] > 0 and d["recall_at_1"] == 1.0 and d["cpu_baseline"] is None
+    assert d["dist"]["ranks_seen"] == 2 and d["dist"]["collective_ms_per_step"] > 0 and "merge" in d["recall_path"]
+    assert d["uncertified_queries"] == 0                        # summed over both shards

@@ -348,6 +348,147 @@ static int salad_run(const uint16_t* patch, long long patch_img_stride, const ui
   return launch_sinkhorn_aggregate(S, F, g, B, n, m, l, t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// f32-accurate SALAD (the reference runs the extractor and the aggregator in fp32: dinov2salad_validation.py:65-66,80-81,
+// `.cuda()` with no cast).  f32 tokens and f32 weights; every linear layer is computed to f32 accuracy on the bf16 matrix
+// pipe by splitting BOTH operands into three bf16 planes, x = h + m + l exactly (8 + 8 + 8 mantissa bits), and keeping the
+// six products whose magnitude is above 2^-24 of the leading one:  (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)  — the dropped
+// ones (m·l, l·m, l·l) are below 2^-26 relative.  bf16 x bf16 products are exact in f32 and the MFMA accumulates in f32,
+// so one ordinary bf16 GEMM over a K axis of 6 x K, smallest terms first, IS the f32 GEMM (error = f32 accumulation
+// order, as in any f32 GEMM).  Hidden activations stay f32 and are split again for the second layers: no bf16 rounding
+// point anywhere between the tokens and the descriptor.  ~6x the MFMA work of the bf16 stage: a precision mode for
+// reference-parity runs (evaluate.*(dtype=torch.float32)), not the benchmark path.
+namespace vpr {
+
+// role 0 = activation operand: planes (l, h, m, m, h, h); role 1 = weight operand: planes (h, l, m, h, m, h)
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long long rows, int K, long long ld_src,
+                                                     int group_rows, long long group_stride,
+                                                     uint16_t* __restrict__ dst, long long ld_dst, int role) {
+  const int k4n = K >> 2;
+  const long long total = rows * k4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / k4n;
+    const int k = (int)(i - r * k4n) << 2;
+    const float* sp = group_rows > 0 ? src + (r / group_rows) * group_stride + (r % group_rows) * ld_src + k
+                                     : src + r * ld_src + k;
+    const float4 v = *reinterpret_cast<const float4*>(sp);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    ushort4 pl[3];
+    uint16_t* ph = reinterpret_cast<uint16_t*>(&pl[0]);
+    uint16_t* pm = reinterpret_cast<uint16_t*>(&pl[1]);
+    uint16_t* pq = reinterpret_cast<uint16_t*>(&pl[2]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint16_t h = f32_to_bf16_bits(x[e]);
+      const float r1 = x[e] - bf16_bits_to_f32(h);          // exact
+      const uint16_t m = f32_to_bf16_bits(r1);
+      const float r2 = r1 - bf16_bits_to_f32(m);            // exact
+      ph[e] = h; pm[e] = m; pq[e] = f32_to_bf16_bits(r2);
+    }
+    uint16_t* dp = dst + r * ld_dst + k;
+    const int order_a[6] = {2, 0, 1, 1, 0, 0}, order_w[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+      *reinterpret_cast<ushort4*>(dp + (long long)p * K) = pl[role ? order_w[p] : order_a[p]];
+  }
+}
+
+static int launch_split3(const float* src, long long rows, int K, long long ld_src, int group_rows, long long group_stride,
+                         uint16_t* dst, long long ld_dst, int role, hipStream_t stream) {
+  if (rows <= 0) return VPR_OK;
+  long long blocks = (rows * (K >> 2) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  VPR_TRY_LAUNCH(launch_kernel(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, rows, K, ld_src, group_rows,
+                               group_stride, dst, ld_dst, role));
+  return VPR_OK;
+}
+
+struct SaladF32Plan {
+  size_t off_A1, off_W1, off_H, off_H2, off_W2s, off_W2c, off_cls, off_W1t, off_Ht, off_Ht2, off_W2t, off_S, off_F, off_g, total;
+};
+static bool salad_f32_plan(int B, int n, int C, int m, int l, int t, int hidden, SaladF32Plan* p) {
+  if (B <= 0 || n <= 0 || C <= 0 || m <= 0 || l <= 0 || t <= 0 || hidden <= 0) return false;
+  const size_t rows = (size_t)B * n;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  p->off_A1 = take(rows * 6 * C * 2);
+  p->off_W1 = take((size_t)2 * hidden * 6 * C * 2);
+  p->off_H = take(rows * 2 * hidden * 4);
+  p->off_H2 = take(rows * 12 * hidden * 2);
+  p->off_W2s = take((size_t)m * 6 * hidden * 2);
+  p->off_W2c = take((size_t)l * 6 * hidden * 2);
+  p->off_cls = take((size_t)B * 6 * C * 2);
+  p->off_W1t = take((size_t)hidden * 6 * C * 2);
+  p->off_Ht = take((size_t)B * hidden * 4);
+  p->off_Ht2 = take((size_t)B * 6 * hidden * 2);
+  p->off_W2t = take((size_t)t * 6 * hidden * 2);
+  p->off_S = take(rows * m * 4);
+  p->off_F = take(rows * l * 4);
+  p->off_g = take((size_t)B * t * 4);
+  p->total = off;
+  return true;
+}
+
+}  // namespace vpr
+
+extern "C" size_t vpr_salad_f32_workspace_bytes(int B, int n, int C, int m, int l, int t, int hidden) {
+  SaladF32Plan p;
+  return salad_f32_plan(B, n, C, m, l, t, hidden, &p) ? p.total : 0;
+}
+
+extern "C" int vpr_salad_aggregate_f32(const float* patch, long long patch_img_stride, const float* cls, long long cls_stride,
+                                       int B, int n, int C, const vpr_salad_weights_f32* w, float dustbin,
+                                       int m, int l, int t, int hidden, int sinkhorn_iters,
+                                       float* out_f32, uint16_t* out_bf16,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+  if (!patch || !cls || !w || !out_f32 || !workspace || B <= 0 || n < 1 || C <= 0) return VPR_ERR_INVALID_ARG;
+  if (!w->w1_sc || !w->b1_sc || !w->w2_s || !w->b2_s || !w->w2_c || !w->b2_c || !w->w1_t || !w->b1_t || !w->w2_t || !w->b2_t)
+    return VPR_ERR_INVALID_ARG;
+  if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || (C % 64) || (hidden % 64)) return VPR_ERR_UNSUPPORTED;
+  if ((patch_img_stride % 4) || (cls_stride % 4) || patch_img_stride < (long long)n * C || cls_stride < C) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(patch) | reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(w->w1_sc) |
+       reinterpret_cast<uintptr_t>(w->w2_s) | reinterpret_cast<uintptr_t>(w->w2_c) | reinterpret_cast<uintptr_t>(w->w1_t) |
+       reinterpret_cast<uintptr_t>(w->w2_t) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+    return VPR_ERR_UNSUPPORTED;
+  SaladF32Plan p;
+  if (!salad_f32_plan(B, n, C, m, l, t, hidden, &p)) return VPR_ERR_INVALID_ARG;
+  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char* ws = static_cast<char*>(workspace);
+  auto u16 = [&](size_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
+  auto f32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  uint16_t *A1 = u16(p.off_A1), *W1 = u16(p.off_W1), *H2 = u16(p.off_H2), *W2s = u16(p.off_W2s), *W2c = u16(p.off_W2c);
+  uint16_t *cls3 = u16(p.off_cls), *W1t = u16(p.off_W1t), *Ht2 = u16(p.off_Ht2), *W2t = u16(p.off_W2t);
+  float *H = f32(p.off_H), *Ht = f32(p.off_Ht), *S = f32(p.off_S), *F = f32(p.off_F), *g = f32(p.off_g);
+  const long long rows = (long long)B * n;
+  const int K1 = 6 * C, K2 = 6 * hidden;
+  // operand planes: tokens (row-group addressing resolved here, A1 is dense), cls rows, all five weight matrices
+  VPR_TRY_LAUNCH(launch_split3(patch, rows, C, C, n, patch_img_stride, A1, K1, 0, stream));
+  VPR_TRY_LAUNCH(launch_split3(cls, B, C, cls_stride, 0, 0, cls3, K1, 0, stream));
+  VPR_TRY_LAUNCH(launch_split3(w->w1_sc, 2 * hidden, C, C, 0, 0, W1, K1, 1, stream));
+  VPR_TRY_LAUNCH(launch_split3(w->w1_t, hidden, C, C, 0, 0, W1t, K1, 1, stream));
+  VPR_TRY_LAUNCH(launch_split3(w->w2_s, m, hidden, hidden, 0, 0, W2s, K2, 1, stream));
+  VPR_TRY_LAUNCH(launch_split3(w->w2_c, l, hidden, hidden, 0, 0, W2c, K2, 1, stream));
+  VPR_TRY_LAUNCH(launch_split3(w->w2_t, t, hidden, hidden, 0, 0, W2t, K2, 1, stream));
+  // layer 1 (f32 out, bias + ReLU in the epilogue)
+  const GemmProblem l1_sc{A1, K1, 0, 0, W1, K1, w->b1_sc, 1, H, 2 * hidden, 0, (int)rows, 2 * hidden, K1, 0, 0};
+  int st = launch_gemm256(l1_sc, stream);
+  if (st == VPR_ERR_UNSUPPORTED) st = launch_gemm_nt_group(&l1_sc, 1, stream);
+  if (st != VPR_OK) return st;
+  const GemmProblem l1_t{cls3, K1, 0, 0, W1t, K1, w->b1_t, 1, Ht, hidden, 0, B, hidden, K1, 0, 0};
+  VPR_TRY_LAUNCH(launch_gemm_nt_group(&l1_t, 1, stream));
+  // hidden activations: f32 -> planes ([score 6h | cluster 6h] per row)
+  VPR_TRY_LAUNCH(launch_split3(H, rows, hidden, 2 * hidden, 0, 0, H2, 2 * K2, 0, stream));
+  VPR_TRY_LAUNCH(launch_split3(H + hidden, rows, hidden, 2 * hidden, 0, 0, H2 + K2, 2 * K2, 0, stream));
+  VPR_TRY_LAUNCH(launch_split3(Ht, B, hidden, hidden, 0, 0, Ht2, K2, 0, stream));
+  const GemmProblem l2[3] = {
+      {H2, 2 * K2, 0, 0, W2s, K2, w->b2_s, 0, S, m, 0, (int)rows, m, K2, 0, 0},
+      {H2 + K2, 2 * K2, 0, 0, W2c, K2, w->b2_c, 0, F, l, 0, (int)rows, l, K2, 0, 0},
+      {Ht2, K2, 0, 0, W2t, K2, w->b2_t, 0, g, t, 0, B, t, K2, 0, 0}};
+  VPR_TRY_LAUNCH(launch_gemm_nt_group(l2, 3, stream));
+  return launch_sinkhorn_aggregate(S, F, g, B, n, m, l, t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
+}
+
 extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
                                    const vpr_salad_weights* w, float dustbin,
                                    int m, int l, int t, int hidden, int sinkhorn_iters,

@@ -55,21 +55,31 @@ def _batches(image_dir: str, filenames, batch_size: int, device):
 def calculate_validation_scores(checkpoint_path: str, val_csv_path: str, image_dir: str, *,
                                 base_model: Optional[DinoV2Salad] = None, arch: str = "vit_base",
                                 scaler: Optional[postproc.LatLonScaler] = None, batch_size: int = 16,
-                                device: str = "cuda", verbose: bool = True, graph: bool = True) -> dict:
+                                device: str = "cuda", verbose: bool = True, graph: bool = True,
+                                dtype: torch.dtype = torch.bfloat16) -> dict:
+    """dtype: torch.bfloat16 (default: the MI355X path — HIP backbone kernels, bf16-operand SALAD) or torch.float32 =
+    the reference's own precision (dinov2salad_validation.py:65-66,80-81: `.cuda()`, no cast): f32 weights, the f32
+    PyTorch block loop (erf GELU, f32 LayerNorm / attention), the f32-accurate SALAD aggregation
+    (vpr_salad_aggregate_f32) and the f32 head — the yardstick the bf16 path is held to (tests/test_precision_gpu.py)."""
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("dtype must be torch.bfloat16 or torch.float32")
     df = _existing_rows(val_csv_path, image_dir)
     dev = torch.device(device)
     if base_model is None:
         base_model = DinoV2Salad(arch)
-    base_model = base_model.to(dev).to(torch.bfloat16).eval()
+    base_model = base_model.to(dev).to(dtype).eval()
     model = DINOv2RegressionModel(base_model).to(dev)
     load_reference_checkpoint(model, checkpoint_path)            # checkpoint['model_state_dict'] or a bare state dict
     model.eval()
-    if hasattr(getattr(base_model, "backbone", None), "fold_layerscale"):
+    if hasattr(getattr(base_model, "backbone", None), "fold_layerscale") and dtype == torch.bfloat16:
         base_model.backbone.gelu = "erf"                         # the checkpoint was trained behind nn.GELU(): exact form, not the GEMM epilogue's tanh
         base_model.backbone.fold_layerscale()                    # AFTER the load (a load un-folds): LayerScale into proj / fc2, enables the HIP backbone path
-    base_model.aggregator.pack()
+    if dtype == torch.bfloat16:
+        base_model.aggregator.pack()
+    else:
+        base_model.aggregator.pack_f32()
     scaler = scaler or postproc.LatLonScaler.campus()
-    prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, torch.bfloat16)   # validation.py:18-22
+    prep = ResizeNormalize(224, "bilinear", HALF_MEAN, HALF_STD, dtype)            # validation.py:18-22
 
     filenames = df["filename"].tolist()
     preds_std = torch.empty((len(filenames), 2), dtype=torch.float32, device=dev)

@@ -6,7 +6,9 @@ The evaluation / gallery-building loops are host-bound once the GPU path is in p
 same GPU time as the eager in-stream forward: `scripts/graph_backbone.py`).
 
 Capture rules the wrapped function must obey (the HIP paths of this package do): no host sync, no `.item()`/`.cpu()`,
-workspaces from `ops.workspace` (allocated during the warm-up calls, outside capture).  The DINOv2 backbone's cls-row
+workspaces from `ops.workspace`.  Those caches are keyed by stream, so the warm-up calls and the capture run on the SAME
+private stream: the buffers the warm-up allocated are the ones the graph addresses (nothing is allocated a second time
+inside the capture), and `close()` — or garbage collection of the wrapper — drops that stream's cache entries again.  The DINOv2 backbone's cls-row
 side stream is switched off inside the captured forward: fork / join branches replay slower than the eager side stream
 (16.2 vs 10.9 ms) while the linear chain replays at the eager in-stream time (11.3 ms); results are bit-identical
 either way (`test_cls_side_chain_is_bit_identical_to_in_stream_path`, `test_graphed_forward_equals_eager`).
@@ -46,7 +48,27 @@ class GraphedForward:
         self.fn, self.warmup = fn, max(1, warmup)
         self._backbones = _backbones(module if module is not None else fn)
         self._graphs: Dict[Tuple, Tuple] = {}
+        self._streams: Dict[int, torch.cuda.Stream] = {}      # device index -> the private warm-up / capture stream
         self.fallback_reason = None          # set when a capture failed: the wrapper then runs the eager forward for good
+
+    def close(self) -> None:
+        """Destroy the graphs and release what the package's stream-keyed caches hold for this wrapper's private
+        streams (workspaces, the backbone's raw-token buffers)."""
+        from . import ops
+        self._graphs.clear()
+        for s in self._streams.values():
+            ops.drop_stream_caches(s.cuda_stream)
+            for b in self._backbones:
+                bufs = b.__dict__.get("_raw_bufs", {})
+                for k in [k for k in bufs if k[1] == s.cuda_stream]:
+                    del bufs[k]
+        self._streams.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                     # noqa: BLE001  interpreter shutdown
+            pass
 
     def _run(self, x):
         saved = [b.cls_side_chain for b in self._backbones]
@@ -67,7 +89,9 @@ class GraphedForward:
         if entry is None:
             static_in = x.clone()
             cur = torch.cuda.current_stream(x.device)
-            side = torch.cuda.Stream(device=x.device)
+            side = self._streams.get(x.device.index)
+            if side is None:
+                side = self._streams[x.device.index] = torch.cuda.Stream(device=x.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):                      # warm-up outside capture: workspaces, module load, plane caches
                 for _ in range(self.warmup):
@@ -76,7 +100,7 @@ class GraphedForward:
             torch.cuda.synchronize(x.device)
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=side):    # the warm-up's stream: its stream-keyed buffers are re-used
                     static_out = self._run(static_in)
             except Exception as e:                             # noqa: BLE001  a forward that cannot be captured (host sync, ...)
                 self.fallback_reason = f"{type(e).__name__}: {e}"

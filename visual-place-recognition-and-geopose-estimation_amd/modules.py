@@ -48,6 +48,7 @@ class SaladAggregator(nn.Module):
                                    nn.Conv2d(hidden, num_clusters, 1))
         self.dust_bin = nn.Parameter(torch.tensor(1.0))
         self._packed: Optional[ops.SaladWeights] = None
+        self._packed_f32: Optional[ops.SaladWeightsF32] = None
 
     def pack(self) -> ops.SaladWeights:
         """Kernel-format weights (bf16 matrices, f32 biases); call again after loading a state dict."""
@@ -62,10 +63,30 @@ class SaladAggregator(nn.Module):
             dustbin=float(self.dust_bin.detach().cpu()))
         return self._packed
 
+    def pack_f32(self) -> ops.SaladWeightsF32:
+        """f32 kernel-format weights for the f32-accurate aggregation (vpr_salad_aggregate_f32): the parameters as they
+        are, no bf16 rounding (the reference keeps the aggregator in fp32: dinov2salad_validation.py:65-66)."""
+        m2 = lambda w: w.detach().reshape(w.shape[0], -1).to(torch.float32).contiguous()
+        f32 = lambda b: b.detach().to(torch.float32).contiguous()
+        s, c, t = self.score, self.cluster_features, self.token_features
+        self._packed_f32 = ops.SaladWeightsF32(
+            w1_sc=torch.cat([m2(s[0].weight), m2(c[0].weight)], 0).contiguous(), b1_sc=f32(torch.cat([s[0].bias, c[0].bias], 0)),
+            w2_s=m2(s[3].weight), b2_s=f32(s[3].bias), w2_c=m2(c[3].weight), b2_c=f32(c[3].bias),
+            w1_t=m2(t[0].weight), b1_t=f32(t[0].bias), w2_t=m2(t[2].weight), b2_t=f32(t[2].bias),
+            dustbin=float(self.dust_bin.detach().cpu()))
+        return self._packed_f32
+
     @torch.no_grad()
     def forward(self, tokens, want_bf16: bool = False):
-        """tokens [B, 1+n, C] bf16 (cls first) or a backbone.SplitTokens pair -> descriptor [B, 8448] f32
-        (and a bf16 copy)."""
+        """tokens [B, 1+n, C] (cls first) or a backbone.SplitTokens pair -> descriptor [B, 8448] f32 (and a bf16 copy).
+        bf16 tokens: the bf16-operand kernels (benchmark path); f32 tokens: the f32-accurate aggregation with f32
+        weights — the reference's precision (its extractor runs in fp32)."""
+        first = tokens.patch if isinstance(tokens, SplitTokens) else tokens
+        if first.dtype == torch.float32:
+            w32 = self._packed_f32 or self.pack_f32()
+            arg = (tokens.patch.contiguous(), tokens.cls.contiguous()) if isinstance(tokens, SplitTokens) else tokens.contiguous()
+            desc, desc16 = ops.salad_aggregate_f32(arg, w32, 3, want_bf16)
+            return (desc, desc16) if want_bf16 else desc
         w = self._packed or self.pack()
         if isinstance(tokens, SplitTokens):
             desc, desc16 = ops.salad_aggregate_split(tokens.patch, tokens.cls, w, 3, want_bf16)
@@ -93,9 +114,9 @@ class DinoV2Salad(nn.Module):
         """images -> descriptor (and its bf16 copy): backbone tokens stay in the layout the backbone
         computed them in (SplitTokens on the HIP path), no re-layout copy before SALAD."""
         t = self.backbone(x, split=True)
-        if t.patch.dtype != torch.bfloat16:
+        if t.patch.dtype not in (torch.bfloat16, torch.float32):
             t = SplitTokens(t.patch.to(torch.bfloat16), t.cls.to(torch.bfloat16))
-        return self.aggregator(t, want_bf16=want_bf16)
+        return self.aggregator(t, want_bf16=want_bf16)          # f32 tokens (an f32 model) take the f32-accurate aggregation
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -247,4 +268,6 @@ def load_reference_checkpoint(model: nn.Module, path: str) -> nn.Module:
     for m in model.modules():
         if hasattr(m, "_packed"):
             m._packed = None
+        if hasattr(m, "_packed_f32"):
+            m._packed_f32 = None
     return model

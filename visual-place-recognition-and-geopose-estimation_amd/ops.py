@@ -69,6 +69,13 @@ def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
     return ent[0]
 
 
+def drop_stream_caches(raw_stream: int) -> None:
+    """Forget every workspace keyed by this stream handle (graphed.GraphedForward.close(): its private stream is gone,
+    and so are the graphs that addressed the buffers)."""
+    for key in [k for k in _WORKSPACES if k[1] == raw_stream]:
+        del _WORKSPACES[key]
+
+
 # ------------------------------------------------------------------------------------------ SALAD
 @dataclass
 class SaladWeights:
@@ -93,6 +100,9 @@ class SaladWeights:
             _need(getattr(self, n), torch.bfloat16, n, 2)
         for n in ("b1_sc", "b2_s", "b2_c", "b1_t", "b2_t"):
             _need(getattr(self, n), torch.float32, n, 1)
+        return self._shapes()
+
+    def _shapes(self) -> Tuple[int, int, int, int, int]:
         hidden2, C = self.w1_sc.shape
         hidden = hidden2 // 2
         m, l, t = self.w2_s.shape[0], self.w2_c.shape[0], self.w2_t.shape[0]
@@ -146,6 +156,53 @@ def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeight
     st = L.vpr_salad_aggregate_split(_ptr(patch), _ptr(cls), B, n, C, ctypes.byref(cw), float(w.dustbin), m, l, t,
                                      hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
     _lib.check(st, "vpr_salad_aggregate_split")
+    return out, out16
+
+
+@dataclass
+class SaladWeightsF32(SaladWeights):
+    """The same ten tensors, all f32 (vpr_salad_weights_f32): operands of the f32-accurate aggregation."""
+
+    def validate(self) -> Tuple[int, int, int, int, int]:
+        for n in ("w1_sc", "w2_s", "w2_c", "w1_t", "w2_t"):
+            _need(getattr(self, n), torch.float32, n, 2)
+        for n in ("b1_sc", "b2_s", "b2_c", "b1_t", "b2_t"):
+            _need(getattr(self, n), torch.float32, n, 1)
+        return self._shapes()
+
+
+def salad_aggregate_f32(tokens, w: SaladWeightsF32, sinkhorn_iters: int = 3,
+                        want_bf16: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """The aggregation at the reference's precision: `tokens` = [B, 1+n, C] f32 (cls first) or a (patch [B,n,C], cls [B,C])
+    pair of f32 tensors, f32 weights -> (descriptor f32 [B, t+l*m], bf16 copy or None).  vpr_salad_aggregate_f32."""
+    if isinstance(tokens, torch.Tensor):
+        _need(tokens, torch.float32, "tokens", 3)
+        B, tpi, Ct = tokens.shape
+        n = tpi - 1
+        patch_ptr, patch_stride = tokens.data_ptr() + 4 * Ct, tpi * Ct
+        cls_ptr, cls_stride = tokens.data_ptr(), tpi * Ct
+        device = tokens.device
+    else:
+        patch, cls = tokens
+        _need(patch, torch.float32, "patch", 3)
+        _need(cls, torch.float32, "cls", 2)
+        B, n, Ct = patch.shape
+        if tuple(cls.shape) != (B, Ct):
+            raise RuntimeError("salad_aggregate_f32: cls must be [B, C]")
+        patch_ptr, patch_stride, cls_ptr, cls_stride = patch.data_ptr(), n * Ct, cls.data_ptr(), Ct
+        device = patch.device
+    C, hidden, m, l, t = w.validate()
+    if Ct != C:
+        raise RuntimeError(f"tokens have C={Ct}, weights expect {C}")
+    L = _lib.lib()
+    ws = workspace("salad_f32", L.vpr_salad_f32_workspace_bytes(B, n, C, m, l, t, hidden), device)
+    out = torch.empty((B, t + l * m), dtype=torch.float32, device=device)
+    out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=device) if want_bf16 else None
+    cw = w.c_struct()
+    st = L.vpr_salad_aggregate_f32(ctypes.c_void_p(patch_ptr), patch_stride, ctypes.c_void_p(cls_ptr), cls_stride, B, n, C,
+                                   ctypes.byref(cw), float(w.dustbin), m, l, t, hidden, int(sinkhorn_iters),
+                                   _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_salad_aggregate_f32")
     return out, out16
 
 

@@ -131,9 +131,18 @@ class ShardedGallery:
         b = q_local.shape[0]
         return v[self.rank * b:(self.rank + 1) * b], i[self.rank * b:(self.rank + 1) * b]
 
-    def uncertified_queries(self) -> int:
-        """Host read (one sync) of the counter: 0 means every answer so far was certified exact on the device."""
-        return int(self.uncertified) if self.uncertified is not None else 0
+    def uncertified_queries(self, reduce: bool = True) -> int:
+        """Host read (one sync) of the counter: 0 means every answer so far was certified exact on the device.
+        The device word counts THIS rank's shard searches only; a query flagged on another rank's shard makes the merged
+        top-k just as unproven, so with a sharded gallery the count is summed over the group (reduce=True: a collective —
+        every rank must call it; reduce=False returns the per-shard count)."""
+        if self.uncertified is None:
+            return 0
+        if reduce and self.collective:
+            total = self.uncertified.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+            return int(total)
+        return int(self.uncertified)
 
 
 class GraphedRetrieval:
@@ -167,8 +176,22 @@ class GraphedRetrieval:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        self._stream = side
+        with torch.cuda.graph(self.graph, stream=side):      # the warm-up's stream: stream-keyed workspaces are re-used, not re-allocated
             self.vals, self.idx = self._run()
+
+    def close(self) -> None:
+        """Destroy the graph and drop the stream-keyed workspaces its private stream left in the package caches."""
+        self.graph = None
+        if self._stream is not None:
+            ops.drop_stream_caches(self._stream.cuda_stream)
+            self._stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                     # noqa: BLE001
+            pass
 
     def _run(self):
         g = self.g
