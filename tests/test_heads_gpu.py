@@ -17,6 +17,7 @@ def _linear_init(out_f, in_f, g):
 @pytest.mark.parametrize("B,D,hidden,n_out,off", [
     (64, 8448, 512, 2, -1),     # DINOv2RegressionModel.regressor
     (64, 8448, 512, 4, 2),      # fused (lat, lon, sin, cos)
+    (64, 8448, 1024, 4, 2),     # bench.py's head: FusedGeoPoseHead of two 512-wide MLPs (hidden 2 x 512)
     (256, 1024, 512, 2, -1),    # Swin-Base MLP head
     (7, 768, 384, 2, 0),        # sin/cos MLP head, ragged batch
     (1, 64, 32, 1, -1),
@@ -74,6 +75,7 @@ def test_zero_pair_normalise_eps(dev):
     (8, 49, 768, torch.float32),      # Swin-T
     (4, 144, 1024, torch.bfloat16),   # Swin-B 384
     (256, 49, 1024, torch.bfloat16),  # BASELINE config 4
+    (256, 144, 1024, torch.bfloat16), # config 4 on the 384-px Swin-B the reference actually used (swin_attempt_2.py:32-33)
     (3, 5, 512, torch.float32),
     (2, 1, 1536, torch.bfloat16),
 ])

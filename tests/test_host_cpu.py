@@ -337,7 +337,11 @@ def test_finetune_angle_head_matches_a_reference_style_loop(unit):
     a = torch.deg2rad(ang)
     tgt = torch.stack([torch.sin(a), torch.cos(a)], 1)                                  # [sin, cos] (:47)
     opt = torch.optim.AdamW(ref.parameters(), lr=5e-2)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+    # the schedulers and clip norms of the two scripts (sin_cos.py:92-93,116; gemini.py:188,215)
+    sched = (torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10) if unit else
+             torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2, eta_min=1e-7))
+    clip = 5.0 if unit else 1.0
+    clipped = 0
     g = torch.Generator().manual_seed(9)
     losses = []
     for epoch in range(4):
@@ -352,10 +356,17 @@ def test_finetune_angle_head_matches_a_reference_style_loop(unit):
                 loss = torch.mean(torch.rad2deg(torch.acos(cs)))
             else:
                 loss = nn.functional.mse_loss(p, tgt[idx])
-            opt.zero_grad(); loss.backward(); opt.step()
+            if unit and torch.isnan(loss):
+                continue
+            opt.zero_grad()
+            loss.backward()
+            clipped += int(torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm=clip) > clip)
+            opt.step()
             tot += float(loss.detach())
         sched.step()
         losses.append(tot / 3)
+    if unit:
+        assert clipped > 0                       # the angular loss is in degrees: the clip at 5.0 is active, as in the reference
     got = [h["train_loss"] for h in out["history"]]
     assert np.allclose(got, losses, rtol=1e-5, atol=1e-6), (got, losses)
     assert out["history"][-1]["val_maae"] < out["history"][0]["val_maae"]

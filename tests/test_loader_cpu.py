@@ -76,3 +76,20 @@ def test_loader_arrow_export_falls_back_for_multi_block_images(tmp_path):
     Image.fromarray(big[::-1].copy()).save(os.path.join(tmp_path, "big1.png"))
     out = list(ImageBatchLoader(str(tmp_path), ["big0.png", "big1.png"], 2, "cpu", workers=2, export="arrow"))
     assert len(out) == 1 and np.array_equal(out[0][2][0].numpy(), big) and np.array_equal(out[0][2][1].numpy(), big[::-1])
+
+
+def test_truncated_jpeg_is_skipped_by_the_test_split_filter(tmp_path, capsys):
+    """evaluate._loadable(decode=True): a JPEG cut in the middle of its scan data passes PIL's verify() but fails at
+    decode; the reference's TestImageDataset.__getitem__ (val_and_test_swin_2.py:150-165) returns None for it and the
+    collate drops the item — the test-split filter must skip it too instead of letting the loader abort the run."""
+    import numpy as np
+    from PIL import Image
+    from vpr_amd import evaluate
+    good, bad = tmp_path / "good.jpg", tmp_path / "bad.jpg"
+    Image.fromarray(np.random.default_rng(0).integers(0, 256, (96, 128, 3), dtype=np.uint8)).save(good, quality=90)
+    data = good.read_bytes()
+    bad.write_bytes(data[: len(data) // 2])
+    assert evaluate._loadable(str(good), decode=True)
+    assert evaluate._loadable(str(bad)) is True                      # verify() alone does not notice
+    assert evaluate._loadable(str(bad), decode=True) is False
+    assert "Skipping invalid/corrupt image file" in capsys.readouterr().out

@@ -140,12 +140,18 @@ def calculate_swin_validation_scores(model, val_csv_path: str, image_dir: str, p
 IMAGE_EXTENSIONS = ["*.jpg", "*.jpeg", "*.png", "*.bmp", "*.gif", "*.JPEG"]        # :44
 
 
-def _loadable(path: str) -> bool:
+def _loadable(path: str, decode: bool = False) -> bool:
     """The reference's per-file check (CampusDataset :73-90 `img.verify()`, TestImageDataset :150-155 returning None
-    for the collate functions :179-195 to drop): a file that PIL cannot open is skipped with a message, not fatal."""
+    for the collate functions :179-195 to drop): a file that PIL cannot open is skipped with a message, not fatal.
+    decode=True (test split): the full decode is attempted as well — the reference's TestImageDataset.__getitem__
+    catches DECODE errors too (a truncated JPEG passes verify() and fails in convert('RGB')) and drops the item,
+    where a verify()-only filter would let the file through and abort the run inside the batch loader."""
     try:
         with Image.open(path) as im:
             im.verify()
+        if decode:
+            with Image.open(path) as im:                     # verify() leaves the object unusable: reopen
+                im.convert("RGB")
         return True
     except Exception as e:                                   # FileNotFoundError, UnidentifiedImageError, OSError, ...
         print(f"Warning: Skipping invalid/corrupt image file: {path} ({e})")
@@ -218,7 +224,7 @@ def validate_and_test_swin(model, val_csv_path: str, val_image_dir: str, test_im
     if not paths:
         print(f"No image files ({', '.join(IMAGE_EXTENSIONS)}) found in {test_image_dir}")                       # :136
         return out
-    tnames = [os.path.basename(p) for p in paths if _loadable(p)]                 # None items dropped by the collate (:189-191)
+    tnames = [os.path.basename(p) for p in paths if _loadable(p, decode=True)]    # None items dropped by the collate (:189-191)
     if not tnames:
         print("No test predictions were made. Check test data directory and image files.")                       # :321
         return out
@@ -285,7 +291,7 @@ def calculate_angle_validation_scores(model, val_csv_path: str, image_dir: str, 
         paths = []
         for ext in IMAGE_EXTENSIONS:
             paths.extend(glob.glob(os.path.join(test_image_dir, ext)))
-        tnames = sorted(os.path.basename(p) for p in paths if _loadable(p))
+        tnames = sorted(os.path.basename(p) for p in paths if _loadable(p, decode=True))
         if tnames:
             tpred = predict_deg(test_image_dir, tnames)
             res.update(test_filenames=tnames, test_pred_deg=tpred)

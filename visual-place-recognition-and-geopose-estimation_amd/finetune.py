@@ -125,12 +125,18 @@ def angle_error_deg(preds: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
 
 def finetune_angle_head(head: nn.Module, features: torch.Tensor, angles_deg, *, unit: bool = True, epochs: int = 20,
                         batch_size: int = 48, lr: float = 1e-5, cosine_t_max: Optional[int] = 10,
+                        grad_clip: Optional[float] = -1.0, warm_restarts: Optional[bool] = None,
                         val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print) -> dict:
     """Head-only training of a sin/cos angle head on cached pooled features (Swin pooler output / DINOv2 CLS token,
     computed once by the HIP path: ops.ln_meanpool_head(..., want_pooled=True) / backbone(x, split=True).cls).
       unit=True   swin_angle_finetuning_sin_cos.py: F.normalize(head(x), eps=1e-6), angular_loss, AdamW(1e-5) with
-                  CosineAnnealingLR(T_max=10) stepped per epoch (:92-93, :119), batches of 48 (:87);
-      unit=False  swin_angle_finetuning_gemini.py / dino_v2_gemini.py: raw (sin, cos), nn.MSELoss (:183).
+                  CosineAnnealingLR(T_max=10) stepped per epoch (:92-93, :119), batches of 48 (:87), a batch whose loss
+                  is NaN is skipped (:110-112), gradients clipped to norm 5.0 before every step (:116 — the loss is in
+                  degrees, so the clip is active);
+      unit=False  swin_angle_finetuning_gemini.py / dino_v2_gemini.py: raw (sin, cos), nn.MSELoss (:183), gradients
+                  clipped to GRAD_CLIP_NORM = 1.0 (:215), CosineAnnealingWarmRestarts(T_0=10, T_mult=2, eta_min=1e-7) (:188).
+    grad_clip: -1 = the script's value for the chosen form (5.0 / 1.0), None = no clipping; warm_restarts: None = the
+    script's scheduler for the chosen form (`cosine_t_max` is T_max resp. T_0; None = no scheduler).
     The backbone stays frozen (the reference fine-tunes it as well: out of scope); `head` is the model's
     `regressor` / `head` sub-module, so the result saves under the reference's state-dict keys."""
     dev = features.device
@@ -139,7 +145,14 @@ def finetune_angle_head(head: nn.Module, features: torch.Tensor, angles_deg, *, 
     for p in head.parameters():
         p.requires_grad_(True)
     opt = torch.optim.AdamW(head.parameters(), lr=lr)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cosine_t_max) if cosine_t_max else None
+    if grad_clip is not None and grad_clip < 0:
+        grad_clip = 5.0 if unit else 1.0
+    if warm_restarts is None:
+        warm_restarts = not unit
+    sched = None
+    if cosine_t_max:
+        sched = (torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=cosine_t_max, T_mult=2, eta_min=1e-7)
+                 if warm_restarts else torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cosine_t_max))
     g = torch.Generator(device="cpu").manual_seed(seed)
     n = features.shape[0]
     fwd = (lambda x: torch.nn.functional.normalize(head(x), dim=1, p=2, eps=1e-6)) if unit else head
@@ -152,11 +165,16 @@ def finetune_angle_head(head: nn.Module, features: torch.Tensor, angles_deg, *, 
         for lo in range(0, n, batch_size):
             idx = perm[lo:lo + batch_size]
             loss = loss_fn(fwd(features[idx]), y[idx])
+            if unit and torch.isnan(loss):
+                log("NaN loss detected! Skipping this batch.")
+                continue
             opt.zero_grad()
             loss.backward()
+            if grad_clip is not None:
+                torch.nn.utils.clip_grad_norm_(head.parameters(), max_norm=grad_clip)
             opt.step()
             total += float(loss.detach())
-            nb += 1
+        nb = max(1, -(-n // batch_size))                        # the scripts divide by len(train_loader), skipped batches included
         if sched is not None:
             sched.step()
         rec = {"epoch": epoch, "train_loss": total / max(nb, 1)}

@@ -29,7 +29,10 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import torch_ops  # noqa: F401  registers torch.ops.vpr.* (torch.library custom ops over the C ABI)
 from .backbone import DinoV2, SplitTokens
+
+_vpr = torch.ops.vpr      # the forwards below call the dispatcher-visible ops (CUDA impl = ctypes -> C ABI; fake impl for tracing)
 
 
 class SaladAggregator(nn.Module):
@@ -84,14 +87,17 @@ class SaladAggregator(nn.Module):
         first = tokens.patch if isinstance(tokens, SplitTokens) else tokens
         if first.dtype == torch.float32:
             w32 = self._packed_f32 or self.pack_f32()
-            arg = (tokens.patch.contiguous(), tokens.cls.contiguous()) if isinstance(tokens, SplitTokens) else tokens.contiguous()
-            desc, desc16 = ops.salad_aggregate_f32(arg, w32, 3, want_bf16)
+            if isinstance(tokens, SplitTokens):
+                patch, cls = tokens.patch.contiguous(), tokens.cls.contiguous()
+            else:
+                patch, cls = tokens[:, 1:].contiguous(), tokens[:, 0].contiguous()
+            desc, desc16 = _vpr.salad_aggregate_f32(patch, cls, torch_ops.weight_list(w32), w32.dustbin, 3)
             return (desc, desc16) if want_bf16 else desc
         w = self._packed or self.pack()
         if isinstance(tokens, SplitTokens):
-            desc, desc16 = ops.salad_aggregate_split(tokens.patch, tokens.cls, w, 3, want_bf16)
+            desc, desc16 = _vpr.salad_aggregate_split(tokens.patch, tokens.cls, torch_ops.weight_list(w), w.dustbin, 3)
         else:
-            desc, desc16 = ops.salad_aggregate(tokens, w, 3, want_bf16)
+            desc, desc16 = _vpr.salad_aggregate(tokens, torch_ops.weight_list(w), w.dustbin, 3)
         return (desc, desc16) if want_bf16 else desc
 
 
@@ -142,7 +148,7 @@ class DINOv2RegressionModel(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         features = self.feature_extractor(x)
-        return ops.pose_head(features.float().contiguous(), *_mlp_head_args(self.regressor))
+        return _vpr.pose_head(features.float().contiguous(), *_mlp_head_args(self.regressor), -1)
 
 
 def _swin_hidden(backbone: nn.Module, pixel_values: torch.Tensor):
@@ -164,10 +170,10 @@ class SwinRegressionModel(nn.Module):
     @torch.no_grad()
     def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
         h, ln = _swin_hidden(self.backbone, pixel_values)
-        _, out = ops.ln_meanpool_head(h, ln.weight.float().contiguous(), ln.bias.float().contiguous(), ln.eps,
-                                      self.regressor.weight.float().contiguous(),
-                                      self.regressor.bias.float().contiguous(),
-                                      0 if self.normalize_output else -1, want_pooled=False)
+        _, out = _vpr.ln_meanpool_head(h, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps,
+                                       self.regressor.weight.detach().float().contiguous(),
+                                       self.regressor.bias.detach().float().contiguous(),
+                                       0 if self.normalize_output else -1)
         return out
 
 
@@ -189,8 +195,9 @@ class SwinMLPRegressionModel(nn.Module):
     @torch.no_grad()
     def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
         h, ln = _swin_hidden(self.backbone, pixel_values)
-        pooled, _ = ops.ln_meanpool_head(h, ln.weight.float().contiguous(), ln.bias.float().contiguous(), ln.eps)
-        return ops.pose_head(pooled, *_mlp_head_args(self.regressor))
+        pooled, _ = _vpr.ln_meanpool_head(h, ln.weight.detach().float().contiguous(), ln.bias.detach().float().contiguous(), ln.eps,
+                                          None, None, -1)
+        return _vpr.pose_head(pooled, *_mlp_head_args(self.regressor), -1)
 
 
 class SwinAngleRegressorSinCos(SwinMLPRegressionModel):
@@ -221,7 +228,8 @@ class DinoV2AngleRegressorSinCos(nn.Module):
     def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
         t = self.backbone(pixel_values, split=True)            # final-norm tokens; the cls rows are a contiguous [B, C]
         pooled = t.cls.float().contiguous()
-        return ops.pose_head(pooled, None, None, self.head.weight.float().contiguous(), self.head.bias.float().contiguous())
+        return _vpr.pose_head(pooled, None, None, self.head.weight.detach().float().contiguous(),
+                              self.head.bias.detach().float().contiguous(), -1)
 
 
 class FusedGeoPoseHead(nn.Module):
@@ -251,7 +259,7 @@ class FusedGeoPoseHead(nn.Module):
     @torch.no_grad()
     def forward(self, features: torch.Tensor) -> torch.Tensor:
         W1, b1, W2, b2 = self._packed or self.pack()
-        return ops.pose_head(features, W1, b1, W2, b2, 2 if self.normalize else -1)
+        return _vpr.pose_head(features, W1, b1, W2, b2, 2 if self.normalize else -1)
 
 
 def load_reference_checkpoint(model: nn.Module, path: str) -> nn.Module:

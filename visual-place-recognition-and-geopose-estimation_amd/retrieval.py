@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from . import torch_ops  # noqa: F401  registers torch.ops.vpr.*
 
 
 def shard_bounds(N: int, rank: int, world: int) -> Tuple[int, int]:
@@ -34,18 +35,27 @@ class HipEngine:
         `uncertified` (int32 [1] on the device) counts queries whose answer the kernels could not certify as the
         exact top-k (include/vpr_amd.h "Checked forms"); no host sync.  score_events: see ops.knn_topk.
         exact_fallback: read the per-query status back (one sync) and re-run flagged queries exhaustively."""
+        plain = ws is None and score_events is None and not exact_fallback      # the dispatcher-visible ops (torch_ops.py)
         if gallery.dtype == torch.uint8:
             if scales is None:
                 raise ValueError("fp8 shard needs per-row scales")
+            if plain:
+                q8, qs = torch.ops.vpr.quantize_fp8_rows(q.float())
+                v, i, _ = torch.ops.vpr.knn_topk_fp8(q8, qs, gallery, scales, k, index_base, norm_bound or ops.NORM_BOUND_FP8,
+                                                     uncertified)
+                return v, i
             q8, qs = ops.quantize_fp8_rows(q.float())
             return ops.knn_topk_fp8(q8, qs, gallery, scales, k, index_base, ws,
                                     norm_bound=norm_bound or ops.NORM_BOUND_FP8, uncertified=uncertified,
                                     score_events=score_events, exact_fallback=exact_fallback)
+        if plain:
+            v, i, _ = torch.ops.vpr.knn_topk(q, gallery, k, index_base, norm_bound or ops.NORM_BOUND_BF16, uncertified)
+            return v, i
         return ops.knn_topk(q, gallery, k, index_base, ws, norm_bound=norm_bound or ops.NORM_BOUND_BF16,
                             uncertified=uncertified, score_events=score_events, exact_fallback=exact_fallback)
 
     def merge(self, vals, idxs):
-        return ops.topk_merge(vals, idxs)
+        return torch.ops.vpr.topk_merge(vals, idxs)
 
 
 def all_gather_topk(v: torch.Tensor, i: torch.Tensor, world: int, group=None):
