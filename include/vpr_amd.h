@@ -98,6 +98,26 @@ int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_
                               float* out_f32, uint16_t* out_bf16,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* The aggregation as its three stages, for callers that overlap them (same kernels, same workspace layout, same result as
+ * the one-call forms above; `workspace` must be the same buffer in all three):
+ *   stage_token      token MLP on the B cls rows                          -> workspace   (reads cls tokens only)
+ *   stage_mlps       score + cluster MLPs on the B*n patch rows           -> workspace   (reads patch tokens only)
+ *   stage_aggregate  Sinkhorn, aggregation, normalisations                -> out_f32 / out_bf16
+ * stage_token and stage_mlps touch disjoint workspace regions and may run concurrently on two streams (the token MLP is a
+ * 10 us weight stream, the MLPs a 40 us all-CU GEMM); stage_aggregate must be ordered after both.
+ * patch row r of image b at patch_tokens + b*patch_img_stride + r*C, cls token of image b at cls_tokens + b*cls_stride
+ * (elements; strides % 8 == 0).  With hidden = 512 the MLP stage is ONE kernel: the second layers are fused into the
+ * layer-1 tile epilogue and leave two partial-sum slabs the aggregation stage adds (no hidden activations in HBM). */
+int vpr_salad_stage_token(const uint16_t* cls_tokens, long long cls_stride, int B, int n, int C,
+                          const vpr_salad_weights* w, int m, int l, int t, int hidden,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int vpr_salad_stage_mlps(const uint16_t* patch_tokens, long long patch_img_stride, int B, int n, int C,
+                         const vpr_salad_weights* w, int m, int l, int t, int hidden,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int vpr_salad_stage_aggregate(int B, int n, int C, float dustbin, int m, int l, int t, int hidden,
+                              int sinkhorn_iters, float* out_f32, uint16_t* out_bf16,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same aggregation at the reference's own precision: f32 tokens, f32 weights, f32-accurate arithmetic end to end
  * (dinov2salad/dinov2salad_validation.py:65-66,80-81 run the extractor in fp32: `.cuda()`, no cast).  Every linear
  * layer runs on the bf16 matrix pipe with both operands split into three bf16 planes (x = h + m + l exactly) and the six

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 # asserted bounds (max abs over the 8448-d unit descriptor, entries ~1e-2)
 HIDDEN_ROUNDING_BOUND = 1e-4      # A: bf16 hidden activations vs none, same operands (north-star tolerance)
 BF16_OPERANDS_BOUND = 2.5e-4      # B: bf16 tokens + weights + hidden vs f64 on the f32 operands
-F32_PATH_BOUND = 2e-6             # B: vpr_salad_aggregate_f32 vs f64 on the f32 operands
+F32_PATH_BOUND = 5e-7             # B: vpr_salad_aggregate_f32 vs f64 on the f32 operands
 # standardised (lat, lon), head outputs O(1)
 E2E_F32_BOUND = 1e-4              # C: f32 path vs torch-f32 backbone + f64 oracle  (north star: within 1e-4)
 E2E_BF16_VS_F32_BOUND = 5e-2      # C: bf16 benchmark path vs the f32 path

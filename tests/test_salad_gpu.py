@@ -127,3 +127,30 @@ def test_salad_larger_scores(dev):
     out, _ = ops.salad_aggregate(tokens.to(dev), _to_dev(w, dev, -2.0), 3)
     assert torch.isfinite(out).all()
     assert (out.cpu().double() - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("C,B", [(1024, 8), (768, 3), (1024, 64)])
+def test_salad_fused_second_layers_equal_unfused_route(dev, tune, C, B):
+    """Round 3: the score / cluster second layers run inside the layer-1 tile epilogue (gemm256_fuse2_kernel: the bf16
+    hidden tile multiplied from LDS with its W2 slice, two partial-sum slabs added by the Sinkhorn kernel) instead of a
+    grouped launch over a 33 MB hidden matrix in HBM.  Same rounding points (hidden activations bf16), other summation
+    order: both routes within TOL of the oracle and within f32 noise of each other; the staged form with the token MLP
+    on a side stream is bit-identical to the one-call form."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(31 * C + B)
+    tokens = torch.randn(B, 257, C, generator=g).to(torch.bfloat16)
+    w = _weights(C, seed=C + 7)
+    ref = osalad.salad_aggregate(tokens, w, dustbin=0.7, iters=3)
+    td, wd = tokens.to(dev), _to_dev(w, dev, 0.7)
+    patch, cls = td[:, 1:].contiguous(), td[:, 0].contiguous()
+    fused, fused16 = ops.salad_aggregate_split(patch, cls, wd, 3, True, overlap=False)
+    staged, staged16 = ops.salad_aggregate_split(patch, cls, wd, 3, True, overlap=True)
+    hub, _ = ops.salad_aggregate(td, wd, 3)                                  # cls-first layout: row-group addressing in the fused kernel
+    tune("VPR_SALAD_VARIANT", 1)
+    unfused, _ = ops.salad_aggregate_split(patch, cls, wd, 3, True, overlap=False)
+    tune("VPR_SALAD_VARIANT", None)
+    e_f, e_u = (fused.cpu().double() - ref).abs().max().item(), (unfused.cpu().double() - ref).abs().max().item()
+    d = (fused - unfused).abs().max().item()
+    print(f"fused vs oracle {e_f:.2e}, unfused vs oracle {e_u:.2e}, fused vs unfused {d:.2e}")
+    assert e_f < TOL and e_u < TOL and d < 5e-6
+    assert torch.equal(staged, fused) and torch.equal(staged16, fused16) and torch.equal(hub, fused)

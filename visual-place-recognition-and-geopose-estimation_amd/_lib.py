@@ -38,6 +38,12 @@ PROTOTYPES = {
     "vpr_salad_aggregate_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(SaladWeightsC), c_float,
                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p]),
+    "vpr_salad_stage_token": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, POINTER(SaladWeightsC), c_int, c_int, c_int, c_int,
+                                      c_void_p, c_size_t, c_void_p]),
+    "vpr_salad_stage_mlps": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, POINTER(SaladWeightsC), c_int, c_int, c_int, c_int,
+                                     c_void_p, c_size_t, c_void_p]),
+    "vpr_salad_stage_aggregate": (c_int, [c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "vpr_salad_f32_workspace_bytes": (c_size_t, [c_int] * 7),
     "vpr_salad_aggregate_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int,
                                         POINTER(SaladWeightsC), c_float, c_int, c_int, c_int, c_int, c_int,

@@ -58,9 +58,12 @@ __device__ __forceinline__ f32x4 g2_mma(const G2Frag& w, const G2Frag& a, f32x4 
 // FP8: pr.A / pr.W point at e4m3 bytes (lda / ldw / K in bytes = elements), pr.a_scale / pr.w_scale are the per-row
 // f32 scales, the output is f32 = acc * a_scale[m] * w_scale[n] (no bias / relu): the kNN score tile of a 512-query
 // gathered batch against an e4m3 shard (BASELINE config 5 on 8 GPUs).
+typedef f32x4 G2Acc[2][2][4][2];   // [qi][qj][rb][cb]: rows n = wc*64 + qj*32 + cb*16 + 4g+e, cols m = wr*128 + qi*64 + rb*16 + lane&15
+
+// Tile mapping, staging set-up and the K loop of one 256 x 256 output tile; returns with every wave past the last MFMA
+// (the two wave groups re-aligned), the accumulators in `acc`, the LDS-DMA tail possibly still in flight.
 template <bool FP8>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G2Acc& acc, int& m0_out, int& n0_out, int& tn_out) {
   constexpr int ES = FP8 ? 1 : 2;                       // operand element size in bytes
   const char* __restrict__ A = reinterpret_cast<const char*>(pr.A);
   const char* __restrict__ W = reinterpret_cast<const char*>(pr.W);
@@ -134,7 +137,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
     for (int j = 0; j < 2; ++j) glds16(src[h][j] + kc * 128, base + dst[h][j]);
   };
 
-  f32x4 acc[2][2][4][2];   // [qi][qj][rb][cb]: rows n = wc*64 + qj*32 + cb*16 + 4g+e, cols m = wr*128 + qi*64 + rb*16 + lane&15
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -222,6 +224,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
     __builtin_amdgcn_s_barrier();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();          // group 0 makes up the barrier group 1 spent at the start
+  m0_out = m0; n0_out = n0; tn_out = tn;
+}
+
+template <bool FP8>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  G2Acc acc;
+  int m0, n0, tn_unused;
+  g2_mainloop<FP8>(pr, smem, acc, m0, n0, tn_unused);
+  const int M = pr.M, N = pr.N;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
   // ---- epilogue ----
   // C/D of (W-operand-as-A): a lane holds n = 4g+e (4 consecutive output columns) at row m = lane&15.
   // Written straight to global that is 32-byte pieces scattered over 16 rows per store; instead the
@@ -309,6 +324,117 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SALAD layer 1 + layer 2 in ONE kernel.  Layer 1 is  H = relu(X W1^T + b1)  with W1 = [score.0 |
+// cluster_features.0] ([2*hidden, C]); the second layers are  S = H[:, :hidden] W2s^T + b2s  ([.., 64]) and
+// F = H[:, hidden:] W2c^T + b2c  ([.., 128]).  A 256 x 256 tile of H is one image's 256 tokens x one quarter of the
+// 2*hidden columns, i.e. a K slice of exactly one of the two second-layer products: the tile's epilogue rounds H to bf16
+// (the rounding point the unfused path has), parks it in the now idle LDS in the operand layout of the main loop (four
+// K-tiles of [256 rows][128 B], same XOR swizzle, so the fragment reads are the conflict-free ones of vpr_common.h),
+// multiplies it with its [n_out, 256] slice of W2 (fragments straight from L2 into registers: 64-128 KB per matrix, shared
+// by all tiles) and writes a PARTIAL sum  out[slab][row][n_out]  (slab = which 256-column slice of the head's hidden
+// layer; slab 0 carries the bias).  The consumer (Sinkhorn kernel) adds the slabs in slab order: deterministic.
+// Gone: the 33.5 MB write + read of H, and the grouped second-layer launch (18.6 us of an 82 us stage).
+struct Fuse2 {
+  const uint16_t* W2[2];       // [n_out[h], hidden] bf16 row-major; h = 0 score head, 1 cluster head
+  const float* b2[2];
+  float* out[2];               // [slabs][M][n_out[h]] f32
+  int n_out[2];                // 64, 128 (multiples of 32, <= 128)
+  int hidden;                  // per-head hidden width: a multiple of 256; tiles_n = 2 * hidden / 256
+};
+
+template <int NOB>             // o-blocks (16 outputs) per wave: n_out / 32
+__device__ __forceinline__ void g2_fuse2_tail(const Fuse2& f, int head, int slab, const char* smem, int m0, int M,
+                                              int lane, int wave) {
+  const int n_out = f.n_out[head];
+  const int mq = wave >> 1, oh = wave & 1;             // 4 row quarters (64 rows) x 2 output halves
+  const int frow = lane & 15, g = lane >> 4;
+  // W2 slice fragments (A operand: i = output o, k = hidden column): 8 k-steps of 32 per 256-column slab
+  const uint16_t* w2 = f.W2[head] + (long long)(oh * (n_out >> 1) + frow) * f.hidden + slab * 256 + 8 * g;
+  bf16x8 wf[NOB][8];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      wf[ob][ks] = *reinterpret_cast<const bf16x8*>(w2 + (long long)ob * 16 * f.hidden + ks * 32);
+  f32x4 acc2[4][NOB];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc2[mb][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                      // every wave's part of the H tile is in LDS
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const char* tile = smem + (ks >> 1) * (G2_BM * TILE_ROW_BYTES);
+    bf16x8 hf[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) hf[mb] = lds_frag(tile, mq * 64 + mb * 16 + frow, g + 4 * (ks & 1));
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        acc2[mb][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ob][ks], hf[mb], acc2[mb][ob], 0, 0, 0);
+  }
+  // D[i = o][j = m]: the lane holds outputs o = 4g .. 4g+3 of row m = lane & 15: one 16-byte store
+  float* outp = f.out[head] + ((long long)slab * M + m0 + mq * 64 + frow) * n_out + oh * (n_out >> 1) + 4 * g;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slab == 0) b = *reinterpret_cast<const float4*>(f.b2[head] + oh * (n_out >> 1) + ob * 16 + 4 * g);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const f32x4 a = acc2[mb][ob];
+      *reinterpret_cast<float4*>(outp + (long long)mb * 16 * n_out + ob * 16) = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_fuse2_kernel(GemmProblem pr, Fuse2 f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  G2Acc acc;
+  int m0, n0, tn;
+  g2_mainloop<false>(pr, smem, acc, m0, n0, tn);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int g = lane >> 4;
+  float4 bias4[2][2];
+#pragma unroll
+  for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+      bias4[qj][cb] = *reinterpret_cast<const float4*>(pr.bias + n0 + wc * 64 + qj * 32 + cb * 16 + 4 * g);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bias + the dummy tail of the LDS-DMA stream
+  __builtin_amdgcn_s_barrier();                      // nobody overwrites the K-tile buffers before every wave's DMA has landed
+  // relu(acc + b1) -> bf16 -> LDS, operand layout: wave column wc owns hidden columns wc*64 .. +63 of the tile = K-tile wc
+  char* kt_base = smem + wc * (G2_BM * TILE_ROW_BYTES);
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int row = wr * 128 + qi * 64 + rb * 16 + (lane & 15);
+#pragma unroll
+      for (int qj = 0; qj < 2; ++qj)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const float4 b = bias4[qj][cb];
+          const f32x4 a = acc[qi][qj][rb][cb];
+          const float v0 = fmaxf(a[0] + b.x, 0.f), v1 = fmaxf(a[1] + b.y, 0.f), v2 = fmaxf(a[2] + b.z, 0.f), v3 = fmaxf(a[3] + b.w, 0.f);
+          uint2 o;
+          o.x = (uint32_t)f32_to_bf16_bits(v0) | ((uint32_t)f32_to_bf16_bits(v1) << 16);
+          o.y = (uint32_t)f32_to_bf16_bits(v2) | ((uint32_t)f32_to_bf16_bits(v3) << 16);
+          const int chunk = qj * 4 + cb * 2 + (g >> 1);
+          *reinterpret_cast<uint2*>(kt_base + tile_off(row, chunk) + (g & 1) * 8) = o;
+        }
+    }
+  const int tiles_per_head = f.hidden >> 8;
+  const int head = tn >= tiles_per_head ? 1 : 0;
+  const int slab = tn - head * tiles_per_head;
+  if (f.n_out[head] == 128) g2_fuse2_tail<4>(f, head, slab, smem, m0, pr.M, lane, wave);
+  else if (f.n_out[head] == 64) g2_fuse2_tail<2>(f, head, slab, smem, m0, pr.M, lane, wave);
+  else g2_fuse2_tail<1>(f, head, slab, smem, m0, pr.M, lane, wave);
+}
+
 constexpr size_t G2_LDS = 128 * (G2_BN * 4 + 16);   // >= the two K-tile buffers (128 KB); sized by the f32 epilogue staging
 
 int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
@@ -326,6 +452,29 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   static PerDeviceFlag attr = {};
   VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<false>), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
+  return VPR_OK;
+}
+
+// SALAD score + cluster MLPs, both layers (see gemm256_fuse2_kernel).  X rows as in GemmProblem (row-group addressing),
+// W1 [2*hidden, C] + b1, second layers W2s [m, hidden] + b2s -> S[slabs][M][m], W2c [l, hidden] + b2c -> F[slabs][M][l],
+// slabs = hidden / 256.  Returns VPR_ERR_UNSUPPORTED for shapes outside the tile geometry (the caller falls back).
+int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long long group_stride, const uint16_t* W1, const float* b1,
+                            const uint16_t* W2s, const float* b2s, const uint16_t* W2c, const float* b2c,
+                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream) {
+  if (!X || !W1 || !b1 || !W2s || !b2s || !W2c || !b2c || !S || !F || M <= 0) return VPR_ERR_INVALID_ARG;
+  if ((M % G2_BM) || (hidden % 256) || hidden <= 0 || (C % 64) || C < 128) return VPR_ERR_UNSUPPORTED;
+  if (!((m == 32 || m == 64 || m == 128) && (l == 32 || l == 64 || l == 128))) return VPR_ERR_UNSUPPORTED;
+  if ((ldx % 8) || (group_rows > 0 && (group_stride % 8))) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2s) |
+       reinterpret_cast<uintptr_t>(W2c) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2s) |
+       reinterpret_cast<uintptr_t>(b2c) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(F)) & 15)
+    return VPR_ERR_UNSUPPORTED;
+  GemmProblem g{X, ldx, group_rows, group_stride, W1, C, b1, 1, nullptr, 0, 1, M, 2 * hidden, C, M / G2_BM, 2 * hidden / G2_BN,
+                nullptr, nullptr, 1, 0};
+  Fuse2 f{{W2s, W2c}, {b2s, b2c}, {S, F}, {m, l}, hidden};
+  static PerDeviceFlag attr = {};
+  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_fuse2_kernel), G2_LDS, attr));
+  VPR_TRY_LAUNCH(launch_kernel(gemm256_fuse2_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g, f));
   return VPR_OK;
 }
 

@@ -41,11 +41,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// NSLAB = 2: scores / feats arrive as two partial-sum slabs (the fused MLP kernel's K slices of the second layers,
+// gemm256_fuse2_kernel), `slab_rows` * m resp. * l elements apart; they are added here, slab 0 first.
+template <int NSLAB>
 __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
-    const float* __restrict__ scores,   // [B, n, m]
-    const float* __restrict__ feats,    // [B, n, l]
+    const float* __restrict__ scores,   // [NSLAB][B, n, m]
+    const float* __restrict__ feats,    // [NSLAB][B, n, l]
     const float* __restrict__ tokfeat,  // [B, t]
-    float dustbin, int iters,
+    long long slab_rows, float dustbin, int iters,
     float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Mx = reinterpret_cast<float*>(smem);        // [65][257]
@@ -67,6 +70,14 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     float4 q[16];
 #pragma unroll
     for (int it = 0; it < 16; ++it) q[it] = sb4[tid + 256 * it];
+    if constexpr (NSLAB == 2) {
+      const float4* sb4b = reinterpret_cast<const float4*>(sb + slab_rows * SA_M);
+      float4 q2[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) q2[it] = sb4b[tid + 256 * it];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) { q[it].x += q2[it].x; q[it].y += q2[it].y; q[it].z += q2[it].z; q[it].w += q2[it].w; }
+    }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int e4 = tid + 256 * it;
@@ -171,14 +182,23 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   const int kh = lane >> 5, li = lane & 31;
   // F comes straight from L2 (32 KB per wave, each value used once): 2 k-steps (32 tokens) per chunk,
   // the next chunk's 16 loads are in flight while the current chunk's 16 MFMAs run.
-  float a_cur[16], a_nxt[16];
+  float a_cur[16], a_nxt[16], b_nxt[16];
+  const float* fb2 = fb + slab_rows * SA_L;
 #pragma unroll
   for (int i = 0; i < 16; ++i) a_cur[i] = fb[(16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+  if constexpr (NSLAB == 2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a_cur[i] += fb2[(16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+  }
 #pragma unroll
   for (int ch = 0; ch < SA_N / 32; ++ch) {
     if (ch + 1 < SA_N / 32) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) a_nxt[i] = fb[(32 * (ch + 1) + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+      if constexpr (NSLAB == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b_nxt[i] = fb2[(32 * (ch + 1) + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+      }
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p1h, acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a_cur[i] = a_nxt[i];
+    for (int i = 0; i < 16; ++i) a_cur[i] = NSLAB == 2 ? a_nxt[i] + b_nxt[i] : a_nxt[i];
   }
 
   // ---- per-cluster L2 norm over l (F.normalize dim=1, eps 1e-12) ----
@@ -258,13 +278,20 @@ constexpr size_t SINKHORN_LDS = SA_PLANES_OFF + 2 * (size_t)SA_M * SA_PLD * size
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
-                              float* out_f32, uint16_t* out_bf16, hipStream_t stream) {
+                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab, long long slab_rows) {
   if (!scores || !feats || !tokfeat || !out_f32 || B <= 0 || iters < 1) return VPR_ERR_INVALID_ARG;
-  if (n != SA_N || m != SA_M || l != SA_L || t != SA_T) return VPR_ERR_UNSUPPORTED;
-  static PerDeviceFlag attr = {};   // > 64 KiB of dynamic LDS needs the opt-in once per device
-  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel), SINKHORN_LDS, attr));
-  VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel, dim3(B), dim3(256), SINKHORN_LDS, stream,
-                     scores, feats, tokfeat, dustbin, iters, out_f32, out_bf16));
+  if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || nslab < 1 || nslab > 2) return VPR_ERR_UNSUPPORTED;
+  if (nslab == 2) {
+    static PerDeviceFlag attr2 = {};   // > 64 KiB of dynamic LDS needs the opt-in once per device
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<2>), SINKHORN_LDS, attr2));
+    VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel<2>, dim3(B), dim3(256), SINKHORN_LDS, stream,
+                       scores, feats, tokfeat, slab_rows, dustbin, iters, out_f32, out_bf16));
+    return VPR_OK;
+  }
+  static PerDeviceFlag attr = {};
+  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<1>), SINKHORN_LDS, attr));
+  VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel<1>, dim3(B), dim3(256), SINKHORN_LDS, stream,
+                     scores, feats, tokfeat, 0LL, dustbin, iters, out_f32, out_bf16));
   return VPR_OK;
 }
 
@@ -274,13 +301,98 @@ struct SaladPlan {
 static bool salad_plan(int B, int n, int C, int m, int l, int t, int hidden, SaladPlan* p) {
   if (B <= 0 || n <= 0 || C <= 0 || m <= 0 || l <= 0 || t <= 0 || hidden <= 0) return false;
   size_t off = 0;
-  p->off_H = off;  off += align_up((size_t)B * n * 2 * hidden * sizeof(uint16_t), 256);
-  p->off_S = off;  off += align_up((size_t)B * n * m * sizeof(float), 256);
-  p->off_F = off;  off += align_up((size_t)B * n * l * sizeof(float), 256);
+  p->off_H = off;  off += align_up((size_t)B * n * 2 * hidden * sizeof(uint16_t), 256);     // unfused route only
+  p->off_S = off;  off += align_up((size_t)2 * B * n * m * sizeof(float), 256);              // up to two partial-sum slabs
+  p->off_F = off;  off += align_up((size_t)2 * B * n * l * sizeof(float), 256);
   p->off_Ht = off; off += align_up((size_t)B * hidden * sizeof(uint16_t), 256);
   p->off_g = off;  off += align_up((size_t)B * t * sizeof(float), 256);
   p->total = off;
   return true;
+}
+
+// Partial-sum slabs the MLP stage leaves in S / F: 2 = second layers fused into the layer-1 tile epilogue
+// (gemm256_fuse2_kernel; hidden = 512 -> two 256-column K slices per head), 1 = separate launches (hidden activations
+// through HBM).  One rule, used by the MLP stage and the aggregation stage.  VPR_SALAD_VARIANT=1 forces the unfused route (A/B).
+static int salad_slabs(int n, int C, int m, int l, int hidden) {
+  if (tune_or(TUNE_SALAD_VARIANT, 0) == 1) return 1;
+  const bool fused = n == SA_N && hidden == 512 && (C % 64) == 0 && C >= 128 && m == SA_M && l == SA_L;
+  return fused ? 2 : 1;
+}
+
+struct SaladArgs {
+  int B, n, C, m, l, t, hidden;
+  const vpr_salad_weights* w;
+  char* ws;
+  SaladPlan p;
+};
+static int salad_args(SaladArgs* a, int B, int n, int C, int m, int l, int t, int hidden, const vpr_salad_weights* w,
+                      void* workspace, size_t workspace_bytes, bool need_w) {
+  if (!workspace || B <= 0 || n < 1 || C <= 0) return VPR_ERR_INVALID_ARG;
+  if (need_w) {
+    if (!w) return VPR_ERR_INVALID_ARG;
+    if (!w->w1_sc || !w->b1_sc || !w->w2_s || !w->b2_s || !w->w2_c || !w->b2_c || !w->w1_t || !w->b1_t || !w->w2_t || !w->b2_t)
+      return VPR_ERR_INVALID_ARG;
+  }
+  if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || (C % 64) || (hidden % 64)) return VPR_ERR_UNSUPPORTED;
+  if (!salad_plan(B, n, C, m, l, t, hidden, &a->p)) return VPR_ERR_INVALID_ARG;
+  if (workspace_bytes < a->p.total) return VPR_ERR_WORKSPACE;
+  a->B = B; a->n = n; a->C = C; a->m = m; a->l = l; a->t = t; a->hidden = hidden; a->w = w;
+  a->ws = static_cast<char*>(workspace);
+  return VPR_OK;
+}
+
+// Stage T: token MLP on the B cls rows -> g [B, t] f32 in the workspace.  Independent of stage M (other inputs, other
+// workspace regions): a caller with two streams runs it beside the big GEMM (ops.salad_aggregate_split does).
+static int salad_stage_token(const SaladArgs& a, const uint16_t* cls, long long cls_stride, hipStream_t stream) {
+  if (!cls) return VPR_ERR_INVALID_ARG;
+  if ((cls_stride % 8) || cls_stride > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
+  uint16_t* Ht = reinterpret_cast<uint16_t*>(a.ws + a.p.off_Ht);
+  float* g = reinterpret_cast<float*>(a.ws + a.p.off_g);
+  const vpr_salad_weights* w = a.w;
+  int st = launch_skinny_linear(cls, (int)cls_stride, w->w1_t, a.C, w->b1_t, 0, 3, Ht, a.hidden, a.B, a.hidden, a.C, nullptr, nullptr, stream);
+  if (st == VPR_ERR_UNSUPPORTED) {
+    const GemmProblem l1{cls, (int)cls_stride, 0, 0, w->w1_t, a.C, w->b1_t, 1, Ht, a.hidden, 1, a.B, a.hidden, a.C, 0, 0};
+    st = launch_gemm_nt_group(&l1, 1, stream);
+  }
+  if (st != VPR_OK) return st;
+  const GemmProblem l2{Ht, a.hidden, 0, 0, w->w2_t, a.hidden, w->b2_t, 0, g, a.t, 0, a.B, a.t, a.hidden, 0, 0};
+  return launch_gemm_nt_group(&l2, 1, stream);
+}
+
+// Stage M: score + cluster MLPs on the B*n patch rows -> S, F (salad_slabs() partial-sum slabs) in the workspace.
+// patch row r of image b at patch + b*patch_img_stride + r*C (addressed in place).
+static int salad_stage_mlps(const SaladArgs& a, const uint16_t* patch, long long patch_img_stride, hipStream_t stream) {
+  if (!patch) return VPR_ERR_INVALID_ARG;
+  if (patch_img_stride % 8) return VPR_ERR_UNSUPPORTED;
+  uint16_t* H = reinterpret_cast<uint16_t*>(a.ws + a.p.off_H);
+  float* S = reinterpret_cast<float*>(a.ws + a.p.off_S);
+  float* F = reinterpret_cast<float*>(a.ws + a.p.off_F);
+  const vpr_salad_weights* w = a.w;
+  const int rows = a.B * a.n, hidden = a.hidden;
+  if (salad_slabs(a.n, a.C, a.m, a.l, hidden) == 2)
+    return launch_salad_mlps_fused(patch, a.C, a.n, patch_img_stride, w->w1_sc, w->b1_sc, w->w2_s, w->b2_s, w->w2_c, w->b2_c,
+                                   S, F, rows, a.C, hidden, a.m, a.l, stream);
+  // unfused: layer 1 on the 256 x 256-tile kernel (34 of SALAD's 38 GFLOP; B tiles x 4 = one full wave of workgroups at
+  // B = 64), hidden activations through HBM as bf16, the two second layers as one grouped launch
+  const GemmProblem l1_sc{patch, a.C, a.n, patch_img_stride, w->w1_sc, a.C, w->b1_sc, 1, H, 2 * hidden, 1, rows, 2 * hidden, a.C, 0, 0};
+  int st = launch_gemm256(l1_sc, stream);
+  if (st == VPR_ERR_UNSUPPORTED) st = launch_gemm_nt_group(&l1_sc, 1, stream);
+  if (st != VPR_OK) return st;
+  const GemmProblem l2[2] = {
+      {H, 2 * hidden, 0, 0, w->w2_s, hidden, w->b2_s, 0, S, a.m, 0, rows, a.m, hidden, 0, 0},
+      {H + hidden, 2 * hidden, 0, 0, w->w2_c, hidden, w->b2_c, 0, F, a.l, 0, rows, a.l, hidden, 0, 0}};
+  return launch_gemm_nt_group(l2, 2, stream);
+}
+
+// Stage A: Sinkhorn + aggregation + normalisations on what stages T and M left in the workspace.
+static int salad_stage_aggregate(const SaladArgs& a, float dustbin, int sinkhorn_iters, float* out_f32, uint16_t* out_bf16,
+                                 hipStream_t stream) {
+  if (!out_f32) return VPR_ERR_INVALID_ARG;
+  const float* S = reinterpret_cast<const float*>(a.ws + a.p.off_S);
+  const float* F = reinterpret_cast<const float*>(a.ws + a.p.off_F);
+  const float* g = reinterpret_cast<const float*>(a.ws + a.p.off_g);
+  return launch_sinkhorn_aggregate(S, F, g, a.B, a.n, a.m, a.l, a.t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream,
+                                   salad_slabs(a.n, a.C, a.m, a.l, a.hidden), (long long)a.B * a.n);
 }
 
 }  // namespace vpr
@@ -300,52 +412,65 @@ extern "C" int vpr_salad_sinkhorn_aggregate(const float* scores, const float* fe
                                    out_f32, out_bf16, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int vpr_salad_stage_token(const uint16_t* cls_tokens, long long cls_stride, int B, int n, int C,
+                                     const vpr_salad_weights* w, int m, int l, int t, int hidden,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  SaladArgs a;
+  VPR_TRY_LAUNCH(salad_args(&a, B, n, C, m, l, t, hidden, w, workspace, workspace_bytes, true));
+  return salad_stage_token(a, cls_tokens, cls_stride, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vpr_salad_stage_mlps(const uint16_t* patch_tokens, long long patch_img_stride, int B, int n, int C,
+                                    const vpr_salad_weights* w, int m, int l, int t, int hidden,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  SaladArgs a;
+  VPR_TRY_LAUNCH(salad_args(&a, B, n, C, m, l, t, hidden, w, workspace, workspace_bytes, true));
+  return salad_stage_mlps(a, patch_tokens, patch_img_stride, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int vpr_salad_stage_aggregate(int B, int n, int C, float dustbin, int m, int l, int t, int hidden,
+                                         int sinkhorn_iters, float* out_f32, uint16_t* out_bf16,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  SaladArgs a;
+  VPR_TRY_LAUNCH(salad_args(&a, B, n, C, m, l, t, hidden, nullptr, workspace, workspace_bytes, false));
+  return salad_stage_aggregate(a, dustbin, sinkhorn_iters, out_f32, out_bf16, static_cast<hipStream_t>(stream));
+}
+
 // patch row r of image b at patch + b*patch_img_stride + r*C; cls token of image b at cls + b*cls_stride
 static int salad_run(const uint16_t* patch, long long patch_img_stride, const uint16_t* cls, long long cls_stride,
                      int B, int n, int C, const vpr_salad_weights* w, float dustbin,
                      int m, int l, int t, int hidden, int sinkhorn_iters,
                      float* out_f32, uint16_t* out_bf16,
                      void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!patch || !cls || !w || !out_f32 || !workspace || B <= 0 || n < 1 || C <= 0)
-    return VPR_ERR_INVALID_ARG;
-  if ((patch_img_stride % 8) || (cls_stride % 8) || cls_stride > 0x7fffffffLL) return VPR_ERR_UNSUPPORTED;
-  if (!w->w1_sc || !w->b1_sc || !w->w2_s || !w->b2_s || !w->w2_c || !w->b2_c || !w->w1_t ||
-      !w->b1_t || !w->w2_t || !w->b2_t)
-    return VPR_ERR_INVALID_ARG;
-  if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || (C % 64) || (hidden % 64))
-    return VPR_ERR_UNSUPPORTED;
-  SaladPlan p;
-  if (!salad_plan(B, n, C, m, l, t, hidden, &p)) return VPR_ERR_INVALID_ARG;
-  if (workspace_bytes < p.total) return VPR_ERR_WORKSPACE;
+  if (!patch || !cls || !out_f32) return VPR_ERR_INVALID_ARG;
+  SaladArgs a;
+  VPR_TRY_LAUNCH(salad_args(&a, B, n, C, m, l, t, hidden, w, workspace, workspace_bytes, true));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  char* ws = static_cast<char*>(workspace);
-  uint16_t* H = reinterpret_cast<uint16_t*>(ws + p.off_H);
-  float* S = reinterpret_cast<float*>(ws + p.off_S);
-  float* F = reinterpret_cast<float*>(ws + p.off_F);
-  uint16_t* Ht = reinterpret_cast<uint16_t*>(ws + p.off_Ht);
-  float* g = reinterpret_cast<float*>(ws + p.off_g);
-  int st;
-  // Layer 1.  The fused score+cluster GEMM on the patch tokens (row r of image b at patch + b*stride + r*C,
-  // addressed in place) is 34 of SALAD's 38 GFLOP: it runs on the 256x256-tile kernel (B tiles x 4 = one
-  // full wave of workgroups at B = 64; 39.5 us vs 57 us on the 128x128 tile).  Token-MLP layer 1 (B rows)
-  // would be two extra workgroups, i.e. a second wave, so it goes through the skinny-rows kernel first.
-  const GemmProblem l1_sc{patch, C, n, patch_img_stride, w->w1_sc, C, w->b1_sc, 1, H, 2 * hidden, 1, B * n, 2 * hidden, C, 0, 0};
-  st = launch_skinny_linear(cls, (int)cls_stride, w->w1_t, C, w->b1_t, 0, 3, Ht, hidden, B, hidden, C, nullptr, nullptr, stream);
-  if (st == VPR_OK) st = launch_gemm256(l1_sc, stream);
-  if (st == VPR_ERR_UNSUPPORTED) {   // shapes outside the two kernels' domains: both on the grouped 128-tile launch
-    const GemmProblem l1[2] = {
-        l1_sc, {cls, (int)cls_stride, 0, 0, w->w1_t, C, w->b1_t, 1, Ht, hidden, 1, B, hidden, C, 0, 0}};
-    st = launch_gemm_nt_group(l1, 2, stream);
-  }
-  if (st != VPR_OK) return st;
-  // Launch 2: the three second layers (scores, cluster features, token features).
-  const GemmProblem l2[3] = {
-      {H, 2 * hidden, 0, 0, w->w2_s, hidden, w->b2_s, 0, S, m, 0, B * n, m, hidden, 0, 0},
-      {H + hidden, 2 * hidden, 0, 0, w->w2_c, hidden, w->b2_c, 0, F, l, 0, B * n, l, hidden, 0, 0},
-      {Ht, hidden, 0, 0, w->w2_t, hidden, w->b2_t, 0, g, t, 0, B, t, hidden, 0, 0}};
-  st = launch_gemm_nt_group(l2, 3, stream);
-  if (st != VPR_OK) return st;
-  return launch_sinkhorn_aggregate(S, F, g, B, n, m, l, t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
+  VPR_TRY_LAUNCH(salad_stage_token(a, cls, cls_stride, stream));
+  VPR_TRY_LAUNCH(salad_stage_mlps(a, patch, patch_img_stride, stream));
+  return salad_stage_aggregate(a, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
+}
+
+extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
+                                   const vpr_salad_weights* w, float dustbin,
+                                   int m, int l, int t, int hidden, int sinkhorn_iters,
+                                   float* out_f32, uint16_t* out_bf16,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!tokens || tokens_per_image < 2 || C <= 0) return VPR_ERR_INVALID_ARG;
+  const long long img_stride = (long long)tokens_per_image * C;
+  return salad_run(tokens + C, img_stride, tokens, img_stride, B, tokens_per_image - 1, C, w, dustbin, m, l, t, hidden,
+                   sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_tokens, int B,
+                                         int patches_per_image, int C,
+                                         const vpr_salad_weights* w, float dustbin,
+                                         int m, int l, int t, int hidden, int sinkhorn_iters,
+                                         float* out_f32, uint16_t* out_bf16,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (patches_per_image < 1 || C <= 0) return VPR_ERR_INVALID_ARG;
+  return salad_run(patch_tokens, (long long)patches_per_image * C, cls_tokens, C, B, patches_per_image, C, w, dustbin,
+                   m, l, t, hidden, sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -487,26 +612,4 @@ extern "C" int vpr_salad_aggregate_f32(const float* patch, long long patch_img_s
       {Ht2, K2, 0, 0, W2t, K2, w->b2_t, 0, g, t, 0, B, t, K2, 0, 0}};
   VPR_TRY_LAUNCH(launch_gemm_nt_group(l2, 3, stream));
   return launch_sinkhorn_aggregate(S, F, g, B, n, m, l, t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream);
-}
-
-extern "C" int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,
-                                   const vpr_salad_weights* w, float dustbin,
-                                   int m, int l, int t, int hidden, int sinkhorn_iters,
-                                   float* out_f32, uint16_t* out_bf16,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-  if (!tokens || tokens_per_image < 2 || C <= 0) return VPR_ERR_INVALID_ARG;
-  const long long img_stride = (long long)tokens_per_image * C;
-  return salad_run(tokens + C, img_stride, tokens, img_stride, B, tokens_per_image - 1, C, w, dustbin, m, l, t, hidden,
-                   sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
-}
-
-extern "C" int vpr_salad_aggregate_split(const uint16_t* patch_tokens, const uint16_t* cls_tokens, int B,
-                                         int patches_per_image, int C,
-                                         const vpr_salad_weights* w, float dustbin,
-                                         int m, int l, int t, int hidden, int sinkhorn_iters,
-                                         float* out_f32, uint16_t* out_bf16,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
-  if (patches_per_image < 1 || C <= 0) return VPR_ERR_INVALID_ARG;
-  return salad_run(patch_tokens, (long long)patches_per_image * C, cls_tokens, C, B, patches_per_image, C, w, dustbin,
-                   m, l, t, hidden, sinkhorn_iters, out_f32, out_bf16, workspace, workspace_bytes, stream);
 }

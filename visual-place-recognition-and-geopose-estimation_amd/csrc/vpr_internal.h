@@ -27,6 +27,11 @@ int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream
 int launch_gemm_nt_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
                        float* C, int ldc, int M, int N, int K, hipStream_t stream);
 int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256.hip: 256x256 tiles, K >= 128
+// gemm256.hip: SALAD score + cluster MLPs with the second layers fused into the layer-1 tile epilogue; S / F receive
+// hidden / 256 partial-sum slabs of [M][m] / [M][l] f32 (slab 0 carries the bias), to be added in slab order
+int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long long group_stride, const uint16_t* W1, const float* b1,
+                            const uint16_t* W2s, const float* b2s, const uint16_t* W2c, const float* b2c,
+                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream);
 // gemm256.hip, fp8 form: e4m3 operands with per-row scales, f32 out (kNN score tile of a >= 384-query gathered batch)
 int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
                        float* C, int ldc, int M, int N, int K, hipStream_t stream, int ksplit = 1, long long slab_stride = 0);
@@ -37,7 +42,7 @@ int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
-                              float* out_f32, uint16_t* out_bf16, hipStream_t stream);
+                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab = 1, long long slab_rows = 0);
 
 // Launch through hipLaunchKernel(), whose return value is THIS launch's status.  (The
 // hipGetLastError() idiom reads a per-thread sticky value that other libraries in the process —

@@ -139,9 +139,24 @@ def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int =
     return out, out16
 
 
+_SALAD_SIDE: dict = {}
+salad_overlap_token_mlp = True      # module switch (A/B: bench.py --no-salad-overlap)
+
+
+def _salad_side_stream(device: torch.device, main_raw: int) -> torch.cuda.Stream:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), main_raw)
+    s = _SALAD_SIDE.get(key)
+    if s is None:
+        s = _SALAD_SIDE[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeights, sinkhorn_iters: int = 3,
-                          want_bf16: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """patch [B, n, C] bf16 + cls [B, C] bf16 -> (descriptor f32 [B, t+l*m], bf16 copy or None)."""
+                          want_bf16: bool = True, overlap: Optional[bool] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """patch [B, n, C] bf16 + cls [B, C] bf16 -> (descriptor f32 [B, t+l*m], bf16 copy or None).
+    overlap (default: on, off while a HIP graph is being captured): the aggregation runs as its three stages with the token
+    MLP (64 cls rows: two 5 us weight streams) on a side stream beside the all-CU score / cluster GEMM, joined before the
+    Sinkhorn stage — same kernels, same workspace, bit-identical result to the one-call form."""
     _need(patch, torch.bfloat16, "patch", 3)
     _need(cls, torch.bfloat16, "cls", 2)
     C, hidden, m, l, t = w.validate()
@@ -153,9 +168,28 @@ def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeight
     out = torch.empty((B, t + l * m), dtype=torch.float32, device=patch.device)
     out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=patch.device) if want_bf16 else None
     cw = w.c_struct()
-    st = L.vpr_salad_aggregate_split(_ptr(patch), _ptr(cls), B, n, C, ctypes.byref(cw), float(w.dustbin), m, l, t,
-                                     hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
-    _lib.check(st, "vpr_salad_aggregate_split")
+    if overlap is None:
+        overlap = salad_overlap_token_mlp and not capturing()
+    if not overlap:
+        st = L.vpr_salad_aggregate_split(_ptr(patch), _ptr(cls), B, n, C, ctypes.byref(cw), float(w.dustbin), m, l, t,
+                                         hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())
+        _lib.check(st, "vpr_salad_aggregate_split")
+        return out, out16
+    dev_idx = patch.device.index if patch.device.index is not None else torch.cuda.current_device()
+    main_raw = _raw_stream(dev_idx)
+    main = torch.cuda.current_stream(patch.device)
+    side = _salad_side_stream(patch.device, main_raw)
+    side.wait_stream(main)                                   # cls (and the workspace's previous consumer) are ready
+    st = L.vpr_salad_stage_token(_ptr(cls), C, B, n, C, ctypes.byref(cw), m, l, t, hidden, _ptr(ws), ws.numel(),
+                                 ctypes.c_void_p(side.cuda_stream))
+    _lib.check(st, "vpr_salad_stage_token")
+    st = L.vpr_salad_stage_mlps(_ptr(patch), n * C, B, n, C, ctypes.byref(cw), m, l, t, hidden, _ptr(ws), ws.numel(),
+                                ctypes.c_void_p(main_raw))
+    _lib.check(st, "vpr_salad_stage_mlps")
+    main.wait_stream(side)
+    st = L.vpr_salad_stage_aggregate(B, n, C, float(w.dustbin), m, l, t, hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16),
+                                     _ptr(ws), ws.numel(), ctypes.c_void_p(main_raw))
+    _lib.check(st, "vpr_salad_stage_aggregate")
     return out, out16
 
 
