@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VPR_AMD_ABI_VERSION 2
+#define VPR_AMD_ABI_VERSION 3
 
 typedef enum vpr_status {
   VPR_OK = 0,
@@ -79,7 +79,17 @@ typedef struct vpr_salad_weights {
   const uint16_t* w2_c;  const float* b2_c;
   const uint16_t* w1_t;  const float* b1_t;
   const uint16_t* w2_t;  const float* b2_t;
+  /* optional (may be NULL): w2_s / w2_c re-laid in MFMA fragment order by vpr_salad_pack_w2_fragments — the fused MLP
+   * kernel then fetches its second-layer operands as contiguous 1 KB wave loads instead of 16 rows x 64 B each */
+  const uint16_t* w2_s_frag;
+  const uint16_t* w2_c_frag;
 } vpr_salad_weights;
+
+/* w2 [n_out, hidden] bf16 row-major -> out (same element count), fragment order of the fused kernel's second GEMM:
+ * out[((((s * (n_out/16) + ob) * 8 + ks) * 64 + lane) * 8 + e] = w2[ob*16 + (lane & 15)][s*256 + ks*32 + 8*(lane >> 4) + e]
+ * (s = 256-column slab of the hidden layer, ob = block of 16 outputs, ks = 32-deep k-step, lane = wavefront lane).
+ * n_out % 16 == 0, hidden % 256 == 0.  Done once per weight set (a 200 KB copy). */
+int vpr_salad_pack_w2_fragments(const uint16_t* w2, int n_out, int hidden, uint16_t* out, void* stream);
 
 size_t vpr_salad_workspace_bytes(int B, int n, int C, int m, int l, int t, int hidden);
 

@@ -154,3 +154,37 @@ def test_salad_fused_second_layers_equal_unfused_route(dev, tune, C, B):
     print(f"fused vs oracle {e_f:.2e}, unfused vs oracle {e_u:.2e}, fused vs unfused {d:.2e}")
     assert e_f < TOL and e_u < TOL and d < 5e-6
     assert torch.equal(staged, fused) and torch.equal(staged16, fused16) and torch.equal(hub, fused)
+    # without the fragment-order copies of W2 (null *_frag members: the kernel reads the row-major matrices): same operands,
+    # same MFMA order -> identical bits
+    ops.salad_use_fragments = False
+    try:
+        plain, _ = ops.salad_aggregate_split(patch, cls, wd, 3, True, overlap=False)
+    finally:
+        ops.salad_use_fragments = True
+    assert torch.equal(plain, fused)
+
+
+@pytest.mark.parametrize("case", ["wide", "dead_column", "hot_row", "all_equal_rows"])
+def test_sinkhorn_exp_domain_survives_extreme_scores(dev, case):
+    """The iterations run in the exp domain (K = exp(M - rowmax), alpha / beta updates): same fixed point and same
+    iterates as the log-domain solver of the oracle.  Score ranges far beyond what the MLPs emit: +-150 spread, a token
+    whose scores all sit 300 below the rest, a cluster whose scores sit 300 above, rows that are constant."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    scores = torch.randn(3, 256, 64, generator=g)
+    if case == "wide":
+        scores = scores * 50.0
+    elif case == "dead_column":
+        scores[:, 17, :] -= 300.0                      # token 17: every cluster score tiny
+    elif case == "hot_row":
+        scores[:, :, 5] += 300.0                       # cluster 5 dominates every token
+    else:
+        scores[:, :, ::2] = 2.5                        # constant rows next to ordinary ones
+    feats = torch.randn(3, 256, 128, generator=g)
+    tok = torch.randn(3, 256, generator=g)
+    ref = osalad.sinkhorn_aggregate(scores, feats, tok, 1.0, 3)
+    out, _ = ops.salad_sinkhorn_aggregate(scores.to(dev), feats.to(dev), tok.to(dev), 1.0, 3)
+    assert torch.isfinite(out).all()
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"{case}: max abs err {err:.2e}")
+    assert err < 5e-6

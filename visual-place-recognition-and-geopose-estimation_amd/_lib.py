@@ -14,13 +14,19 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 STATUS_OK = 0
 
 
 class SaladWeightsC(Structure):
-    """struct vpr_salad_weights (device pointers)."""
+    """struct vpr_salad_weights (device pointers; the two *_frag members may be null)."""
+    _fields_ = [(n, c_void_p) for n in
+                ("w1_sc", "b1_sc", "w2_s", "b2_s", "w2_c", "b2_c", "w1_t", "b1_t", "w2_t", "b2_t", "w2_s_frag", "w2_c_frag")]
+
+
+class SaladWeightsF32C(Structure):
+    """struct vpr_salad_weights_f32 (device pointers)."""
     _fields_ = [(n, c_void_p) for n in
                 ("w1_sc", "b1_sc", "w2_s", "b2_s", "w2_c", "b2_c", "w1_t", "b1_t", "w2_t", "b2_t")]
 
@@ -45,8 +51,9 @@ PROTOTYPES = {
     "vpr_salad_stage_aggregate": (c_int, [c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p]),
     "vpr_salad_f32_workspace_bytes": (c_size_t, [c_int] * 7),
+    "vpr_salad_pack_w2_fragments": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vpr_salad_aggregate_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int,
-                                        POINTER(SaladWeightsC), c_float, c_int, c_int, c_int, c_int, c_int,
+                                        POINTER(SaladWeightsF32C), c_float, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_salad_sinkhorn_aggregate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                              c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -335,77 +335,71 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
 // by all tiles) and writes a PARTIAL sum  out[slab][row][n_out]  (slab = which 256-column slice of the head's hidden
 // layer; slab 0 carries the bias).  The consumer (Sinkhorn kernel) adds the slabs in slab order: deterministic.
 // Gone: the 33.5 MB write + read of H, and the grouped second-layer launch (18.6 us of an 82 us stage).
+#ifdef VPR_ABLATION
+__device__ long long* g_fuse2_clocks = nullptr;      // timing-only build: phase clocks of gemm256_fuse2_kernel, [tiles][8]
+#define G2_CLOCK(k) do { if (g_fuse2_clocks && threadIdx.x == 0) g_fuse2_clocks[blockIdx.x * 8 + (k)] = vpr_clock_now(); } while (0)
+#else
+#define G2_CLOCK(k) do { } while (0)
+#endif
+
 struct Fuse2 {
   const uint16_t* W2[2];       // [n_out[h], hidden] bf16 row-major; h = 0 score head, 1 cluster head
+  const uint16_t* W2frag[2];   // the same matrices in fragment order (vpr_salad_pack_w2_fragments) or null
   const float* b2[2];
   float* out[2];               // [slabs][M][n_out[h]] f32
-  int n_out[2];                // 64, 128 (multiples of 32, <= 128)
+  int n_out[2];                // 64 or 128 each
   int hidden;                  // per-head hidden width: a multiple of 256; tiles_n = 2 * hidden / 256
 };
 
-template <int NOB>             // o-blocks (16 outputs) per wave: n_out / 32
-__device__ __forceinline__ void g2_fuse2_tail(const Fuse2& f, int head, int slab, const char* smem, int m0, int M,
-                                              int lane, int wave) {
+// Epilogue of gemm256_fuse2_kernel.  NOB = o-blocks (16 outputs) per wave = n_out / 64.
+// Work split of the second GEMM ([256 rows] x [n_out] x [K = 256 hidden columns of this tile]): 2 row halves x 4 output
+// quarters.  A wave keeps its W2 fragments in registers (NOB x 8 k-steps x 16 B per lane: 16 / 8 KB per wave, each
+// fragment needed by exactly 2 waves) and reads the hidden tile from LDS (8 row blocks x 8 k-steps).  The first cut
+// (4 row quarters x 2 output halves) pulled every W2 fragment through four waves — 256 KB per workgroup out of an L2 that
+// all 256 workgroups hit at the same addresses at the same moment: 3.9 / 7.4 us (score / cluster tiles) waiting for it
+// (phase clocks, scripts/sinkhorn_phases.py).  Here the fragments are requested BEFORE the hidden tile is parked in LDS
+// (the main loop's LDS-DMA tail is older in the in-order vmcnt queue, so a counted wait still retires exactly the tail).
+template <int NOB>
+__device__ __forceinline__ void g2_fuse2_epilogue(const GemmProblem& pr, const Fuse2& f, G2Acc& acc, char* smem,
+                                                  int head, int slab, int m0, int n0, int lane, int wave) {
   const int n_out = f.n_out[head];
-  const int mq = wave >> 1, oh = wave & 1;             // 4 row quarters (64 rows) x 2 output halves
-  const int frow = lane & 15, g = lane >> 4;
-  // W2 slice fragments (A operand: i = output o, k = hidden column): 8 k-steps of 32 per 256-column slab
-  const uint16_t* w2 = f.W2[head] + (long long)(oh * (n_out >> 1) + frow) * f.hidden + slab * 256 + 8 * g;
-  bf16x8 wf[NOB][8];
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-      wf[ob][ks] = *reinterpret_cast<const bf16x8*>(w2 + (long long)ob * 16 * f.hidden + ks * 32);
-  f32x4 acc2[4][NOB];
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) acc2[mb][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();                                      // every wave's part of the H tile is in LDS
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const char* tile = smem + (ks >> 1) * (G2_BM * TILE_ROW_BYTES);
-    bf16x8 hf[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) hf[mb] = lds_frag(tile, mq * 64 + mb * 16 + frow, g + 4 * (ks & 1));
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int ob = 0; ob < NOB; ++ob)
-        acc2[mb][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ob][ks], hf[mb], acc2[mb][ob], 0, 0, 0);
-  }
-  // D[i = o][j = m]: the lane holds outputs o = 4g .. 4g+3 of row m = lane & 15: one 16-byte store
-  float* outp = f.out[head] + ((long long)slab * M + m0 + mq * 64 + frow) * n_out + oh * (n_out >> 1) + 4 * g;
-#pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (slab == 0) b = *reinterpret_cast<const float4*>(f.b2[head] + oh * (n_out >> 1) + ob * 16 + 4 * g);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const f32x4 a = acc2[mb][ob];
-      *reinterpret_cast<float4*>(outp + (long long)mb * 16 * n_out + ob * 16) = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
-    }
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void gemm256_fuse2_kernel(GemmProblem pr, Fuse2 f) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  G2Acc acc;
-  int m0, n0, tn;
-  g2_mainloop<false>(pr, smem, acc, m0, n0, tn);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int g = lane >> 4;
+  const int frow = lane & 15, g = lane >> 4;
+  const int mh = wave >> 2, oq = wave & 3;              // second GEMM: row half (128 rows), output quarter (16 * NOB outputs)
+  // layer-1 bias first, then the W2 fragments: vmcnt retires in order, so the staging code below can wait for the bias
+  // (needed at once) with the NOB * 8 younger fragment loads still in flight behind it
   float4 bias4[2][2];
 #pragma unroll
   for (int qj = 0; qj < 2; ++qj)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
       bias4[qj][cb] = *reinterpret_cast<const float4*>(pr.bias + n0 + wc * 64 + qj * 32 + cb * 16 + 4 * g);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bias + the dummy tail of the LDS-DMA stream
+  // W2 slice fragments (A operand: i = output o, k = hidden column): 8 k-steps of 32 per 256-column slab.
+  // Fragment-order copy (vpr_salad_pack_w2_fragments): one contiguous 1 KB per wave load.  Row-major original: a wave
+  // load touches 16 rows x 64 B = 16 cache lines for 1 KB, and the L1's tag rate then sets the pace — 4 / 7 us of
+  // waiting per score / cluster tile (phase clocks) against 1 us with the packed copy.
+  bf16x8 wf[NOB][8];
+  if (f.W2frag[head] != nullptr) {
+    const uint16_t* wp = f.W2frag[head] + ((long long)(slab * (n_out >> 4) + oq * NOB) * 8 * 64 + lane) * 8;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        wf[ob][ks] = *reinterpret_cast<const bf16x8*>(wp + (ob * 8 + ks) * 512);
+  } else {
+    const uint16_t* w2 = f.W2[head] + (long long)(oq * 16 * NOB + frow) * f.hidden + slab * 256 + 8 * g;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        wf[ob][ks] = *reinterpret_cast<const bf16x8*>(w2 + (long long)ob * 16 * f.hidden + ks * 32);
+  }
+  // the 4 + NOB * 8 loads above are the youngest entries of the vmcnt queue: everything older (the dummy tail of the
+  // LDS-DMA stream) has landed once only they are outstanding
+  if constexpr (NOB == 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // nobody overwrites the K-tile buffers before every wave's DMA has landed
+  G2_CLOCK(2);
   // relu(acc + b1) -> bf16 -> LDS, operand layout: wave column wc owns hidden columns wc*64 .. +63 of the tile = K-tile wc
   char* kt_base = smem + wc * (G2_BM * TILE_ROW_BYTES);
 #pragma unroll
@@ -427,12 +421,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_fuse2_kernel(GemmProblem pr, F
           *reinterpret_cast<uint2*>(kt_base + tile_off(row, chunk) + (g & 1) * 8) = o;
         }
     }
+  f32x4 acc2[8][NOB];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc2[mb][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();                                      // the whole hidden tile is in LDS (and the W2 fragments have arrived)
+  G2_CLOCK(3);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const char* tile = smem + (ks >> 1) * (G2_BM * TILE_ROW_BYTES);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const bf16x8 hf = lds_frag(tile, mh * 128 + mb * 16 + frow, g + 4 * (ks & 1));
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob)
+        acc2[mb][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ob][ks], hf, acc2[mb][ob], 0, 0, 0);
+    }
+  }
+  G2_CLOCK(4);
+  // D[i = o][j = m]: the lane holds outputs o = 4g .. 4g+3 of row m = lane & 15: one 16-byte store
+  float* outp = f.out[head] + ((long long)slab * pr.M + m0 + mh * 128 + frow) * n_out + oq * 16 * NOB + 4 * g;
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slab == 0) b = *reinterpret_cast<const float4*>(f.b2[head] + oq * 16 * NOB + ob * 16 + 4 * g);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const f32x4 a = acc2[mb][ob];
+      *reinterpret_cast<float4*>(outp + (long long)mb * 16 * n_out + ob * 16) = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_fuse2_kernel(GemmProblem pr, Fuse2 f) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  G2Acc acc;
+  int m0, n0, tn;
+  G2_CLOCK(0);
+  g2_mainloop<false>(pr, smem, acc, m0, n0, tn);
+  G2_CLOCK(1);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_per_head = f.hidden >> 8;
   const int head = tn >= tiles_per_head ? 1 : 0;
   const int slab = tn - head * tiles_per_head;
-  if (f.n_out[head] == 128) g2_fuse2_tail<4>(f, head, slab, smem, m0, pr.M, lane, wave);
-  else if (f.n_out[head] == 64) g2_fuse2_tail<2>(f, head, slab, smem, m0, pr.M, lane, wave);
-  else g2_fuse2_tail<1>(f, head, slab, smem, m0, pr.M, lane, wave);
+  if (f.n_out[head] == 128) g2_fuse2_epilogue<2>(pr, f, acc, smem, head, slab, m0, n0, lane, wave);
+  else g2_fuse2_epilogue<1>(pr, f, acc, smem, head, slab, m0, n0, lane, wave);
+  G2_CLOCK(5);
 }
 
 constexpr size_t G2_LDS = 128 * (G2_BN * 4 + 16);   // >= the two K-tile buffers (128 KB); sized by the f32 epilogue staging
@@ -455,15 +491,39 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   return VPR_OK;
 }
 
+__global__ __launch_bounds__(256) void pack_w2_fragments_kernel(const uint16_t* __restrict__ w2, int n_out, int hidden,
+                                                                uint16_t* __restrict__ out) {
+  // one thread per 16-byte fragment piece: index = ((s * (n_out/16) + ob) * 8 + ks) * 64 + lane
+  const long long total = (long long)n_out * hidden / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), ks = (int)((i >> 6) & 7);
+    const long long r = i >> 9;
+    const int nob = n_out >> 4;
+    const int ob = (int)(r % nob), sl = (int)(r / nob);
+    const uint16_t* src = w2 + (long long)(ob * 16 + (lane & 15)) * hidden + sl * 256 + ks * 32 + 8 * (lane >> 4);
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(src);
+  }
+}
+
+int launch_pack_w2_fragments(const uint16_t* w2, int n_out, int hidden, uint16_t* out, hipStream_t stream) {
+  if (!w2 || !out || n_out <= 0 || hidden <= 0) return VPR_ERR_INVALID_ARG;
+  if ((n_out % 16) || (hidden % 256)) return VPR_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(out)) & 15) return VPR_ERR_UNSUPPORTED;
+  const long long total = (long long)n_out * hidden / 8;
+  VPR_TRY_LAUNCH(launch_kernel(pack_w2_fragments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w2, n_out, hidden, out));
+  return VPR_OK;
+}
+
 // SALAD score + cluster MLPs, both layers (see gemm256_fuse2_kernel).  X rows as in GemmProblem (row-group addressing),
 // W1 [2*hidden, C] + b1, second layers W2s [m, hidden] + b2s -> S[slabs][M][m], W2c [l, hidden] + b2c -> F[slabs][M][l],
 // slabs = hidden / 256.  Returns VPR_ERR_UNSUPPORTED for shapes outside the tile geometry (the caller falls back).
 int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long long group_stride, const uint16_t* W1, const float* b1,
                             const uint16_t* W2s, const float* b2s, const uint16_t* W2c, const float* b2c,
-                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream) {
+                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream,
+                            const uint16_t* W2s_frag, const uint16_t* W2c_frag) {
   if (!X || !W1 || !b1 || !W2s || !b2s || !W2c || !b2c || !S || !F || M <= 0) return VPR_ERR_INVALID_ARG;
   if ((M % G2_BM) || (hidden % 256) || hidden <= 0 || (C % 64) || C < 128) return VPR_ERR_UNSUPPORTED;
-  if (!((m == 32 || m == 64 || m == 128) && (l == 32 || l == 64 || l == 128))) return VPR_ERR_UNSUPPORTED;
+  if (!((m == 64 || m == 128) && (l == 64 || l == 128))) return VPR_ERR_UNSUPPORTED;      // 16 or 32 outputs per wave quarter
   if ((ldx % 8) || (group_rows > 0 && (group_stride % 8))) return VPR_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2s) |
        reinterpret_cast<uintptr_t>(W2c) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2s) |
@@ -471,13 +531,19 @@ int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long lon
     return VPR_ERR_UNSUPPORTED;
   GemmProblem g{X, ldx, group_rows, group_stride, W1, C, b1, 1, nullptr, 0, 1, M, 2 * hidden, C, M / G2_BM, 2 * hidden / G2_BN,
                 nullptr, nullptr, 1, 0};
-  Fuse2 f{{W2s, W2c}, {b2s, b2c}, {S, F}, {m, l}, hidden};
+  if ((reinterpret_cast<uintptr_t>(W2s_frag) | reinterpret_cast<uintptr_t>(W2c_frag)) & 15) return VPR_ERR_UNSUPPORTED;
+  Fuse2 f{{W2s, W2c}, {W2s_frag, W2c_frag}, {b2s, b2c}, {S, F}, {m, l}, hidden};
   static PerDeviceFlag attr = {};
   VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_fuse2_kernel), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_fuse2_kernel, dim3(g.tiles_m * g.tiles_n), dim3(512), G2_LDS, stream, g, f));
   return VPR_OK;
 }
 
+#ifdef VPR_ABLATION
+extern "C" int vpr_gemm256_fuse2_set_clocks(long long* clocks) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fuse2_clocks), &clocks, sizeof(clocks)) == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+#endif
 // e4m3 operands with per-row scales, f32 out: C[m][n] = a_scale[m] * w_scale[n] * sum_k A[m][k] W[n][k]; K % 128 == 0, K >= 256.
 int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
                        float* C, int ldc, int M, int N, int K, hipStream_t stream, int ksplit, long long slab_stride) {
@@ -498,6 +564,10 @@ int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const ui
 }  // namespace vpr
 
 using namespace vpr;
+
+extern "C" int vpr_salad_pack_w2_fragments(const uint16_t* w2, int n_out, int hidden, uint16_t* out, void* stream) {
+  return launch_pack_w2_fragments(w2, n_out, hidden, out, static_cast<hipStream_t>(stream));
+}
 
 // Same contract as vpr_gemm_nt_bf16 (K >= 128, ldc % 4 == 0, C 16-byte aligned), 256 x 256 tiles.
 extern "C" int vpr_gemm256_nt_bf16(const uint16_t* A, int lda, int a_group_rows, long long a_group_stride,

@@ -30,7 +30,15 @@ constexpr int SA_L = 128;   // cluster dim
 constexpr int SA_T = 256;   // token dim
 constexpr int SA_LD = SA_N + 1;   // LDS row stride (words) of the [m+1][n] score matrix
 constexpr int SA_PLD = SA_N + 8;  // row stride (bf16) of the P planes: 528 B, 16-byte aligned rows, rows 4 banks apart
-constexpr size_t SA_PLANES_OFF = (((SA_M + 1) * SA_LD + 68 + SA_N + 4 * SA_M + 4) * sizeof(float) + 15) / 16 * 16;
+// LDS: [score matrix 65 x 257 f32  |  later: two P planes 64 x 264 bf16]  then the small arrays (alpha / beta / norms)
+constexpr size_t SA_BIG_BYTES = ((SA_M + 1) * SA_LD * sizeof(float) > 2 * SA_M * SA_PLD * sizeof(uint16_t)
+                                     ? (SA_M + 1) * SA_LD * sizeof(float) : 2 * SA_M * SA_PLD * sizeof(uint16_t));
+constexpr size_t SA_SMALL_OFF = (SA_BIG_BYTES + 15) / 16 * 16;
+
+// value of lane `i` (compile-time constant) of a wave-distributed register, as a scalar operand: v_readlane_b32
+__device__ __forceinline__ float lane_bcast(float v, int i) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // deterministic: wave butterflies, then a fixed-order sum of the 4 wave totals
@@ -43,6 +51,33 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 // NSLAB = 2: scores / feats arrive as two partial-sum slabs (the fused MLP kernel's K slices of the second layers,
 // gemm256_fuse2_kernel), `slab_rows` * m resp. * l elements apart; they are added here, slab 0 first.
+//
+// Round 3 restructure (29 -> ~15 us at B = 64 with two slabs):
+//  * every global load of the kernel — the score slabs AND all 128 KB (x NSLAB) of cluster features — is issued in the
+//    first microsecond; the old kernel fetched the features chunk by chunk behind the iterations, eight dependent round
+//    trips of ~1 us each;
+//  * the iterations run in the exp domain.  With K_ij = exp(M_ij - r_i), r_i = max_j M_ij, alpha_i = exp(u_i + r_i),
+//    beta_j = exp(v_j), the log-domain updates u = log a - LSE_j(M + v), v = log b - LSE_i(M + u) are exactly
+//        alpha_i = a_i / sum_j K_ij beta_j,      beta_j = b_j / sum_i K_ij alpha_i        (beta = 1 at the start),
+//    i.e. one exp per matrix entry ONCE instead of two per entry per iteration (the iterations were exp-issue-bound:
+//    2.6 us each), and P = K alpha beta (n + m).  Range: every row holds a K = 1 (its maximum) and so does every column
+//    (the dustbin row is constant, so K = 1 along it): all sums are >= one O(1) term and alpha, beta stay within a few
+//    orders of magnitude of 1 for any finite scores; entries more than e^87 below their row maximum flush to 0, which is
+//    where the log-domain form's exp(x - max) puts them too.
+//  * the two bf16 planes of P re-use the LDS of the score matrix (dead once K sits in registers);
+//  * barriers up to the aggregation order LDS traffic only (lds_barrier(): no vmcnt(0)), so the 128-256 KB of cluster
+//    features keep streaming in behind the score-dependent critical path instead of being waited for at the first
+//    __syncthreads() (a CU pulls ~70 GB/s: 384 KB of input are 5.6 us when waited for up front).
+// Phase clocks (timing-only build: `make ablation`, scripts/sinkhorn_phases.py): with VPR_ABLATION defined, thread 0 of
+// every workgroup stores s_memrealtime (100 MHz) at the phase boundaries into a 16-slot record behind the bf16 output pointer's twin
+// (g_sinkhorn_clocks, set through vpr_salad_sinkhorn_set_clocks); compiled out of the shipped library.
+#ifdef VPR_ABLATION
+__device__ long long* g_sinkhorn_clocks = nullptr;
+#define SA_CLOCK(k) do { if (g_sinkhorn_clocks && threadIdx.x == 0) g_sinkhorn_clocks[blockIdx.x * 16 + (k)] = vpr_clock_now(); } while (0)
+#else
+#define SA_CLOCK(k) do { } while (0)
+#endif
+
 template <int NSLAB>
 __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     const float* __restrict__ scores,   // [NSLAB][B, n, m]
@@ -51,55 +86,74 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     long long slab_rows, float dustbin, int iters,
     float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Mx = reinterpret_cast<float*>(smem);        // [65][257]
-  float* u = Mx + (SA_M + 1) * SA_LD;                // [65] (+3 pad)
-  float* v = u + 68;                                 // [256]
-  float* ssq = v + SA_N;                             // [4][64]
-  float* red = ssq + 4 * SA_M;                       // [4]
-  uint16_t* Phi = reinterpret_cast<uint16_t*>(smem + SA_PLANES_OFF);   // [64][SA_PLD] bf16: hi plane of P (16-byte aligned)
+  float* Mx = reinterpret_cast<float*>(smem);        // [65][257] raw scores; later the two P planes
+  uint16_t* Phi = reinterpret_cast<uint16_t*>(smem);      // [64][SA_PLD] bf16: hi plane of P (16-byte aligned rows)
   uint16_t* Plo = Phi + SA_M * SA_PLD;                    // lo plane: P = hi + lo to 2^-17
+  float* al = reinterpret_cast<float*>(smem + SA_SMALL_OFF);   // [65] (+3 pad): row maxima, then alpha
+  float* be = al + 68;                               // [256] beta
+  float* ssq = be + SA_N;                            // [4][64]
+  float* red = ssq + 4 * SA_M;                       // [4]
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int D_OUT = SA_T + SA_L * SA_M;
 
-  // ---- load scores transposed: Mx[i][j] = scores[b][j][i]; dustbin row i = m ----
+  SA_CLOCK(0);
+  // ---- all global loads up front ----
   const float* sb = scores + (long long)b * SA_N * SA_M;
-  {
-    // 16-B loads, all 16 of a thread in flight at once; 4 scattered LDS stores each
-    const float4* sb4 = reinterpret_cast<const float4*>(sb);
-    float4 q[16];
+  const float4* sb4 = reinterpret_cast<const float4*>(sb);
+  float4 q[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) q[it] = sb4[tid + 256 * it];
-    if constexpr (NSLAB == 2) {
-      const float4* sb4b = reinterpret_cast<const float4*>(sb + slab_rows * SA_M);
-      float4 q2[16];
+  for (int it = 0; it < 16; ++it) q[it] = sb4[tid + 256 * it];
+  if constexpr (NSLAB == 2) {
+    const float4* sb4b = reinterpret_cast<const float4*>(sb + slab_rows * SA_M);
+    float4 q2[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) q2[it] = sb4b[tid + 256 * it];
+    for (int it = 0; it < 16; ++it) q2[it] = sb4b[tid + 256 * it];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) { q[it].x += q2[it].x; q[it].y += q2[it].y; q[it].z += q2[it].z; q[it].w += q2[it].w; }
-    }
+    for (int it = 0; it < 16; ++it) { q[it].x += q2[it].x; q[it].y += q2[it].y; q[it].z += q2[it].z; q[it].w += q2[it].w; }
+  }
+  // cluster features of this wave's 32 cluster-dim rows, all 256 tokens (32x32x16 A-operand map:
+  // A[i = lane & 31][k = 8 * (lane >> 5) + e]); token = 32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7).
+  // (Tried: requesting them in chunks of 32 loads spread over the score-dependent phases, so that the wave never stalls
+  // on its 64-entry load queue — the phases just shift: what bounds the front of this kernel is the ~70 GB/s one CU
+  // pulls, 192-384 KB of input, not the order of the requests.)
+  const float* fb = feats + (long long)b * SA_N * SA_L;
+  const int l0 = 32 * wave;
+  const int kh = lane >> 5, li = lane & 31;
+  float fa[SA_N / 32][16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int e4 = tid + 256 * it;
-      const int j = e4 >> 4, i = (e4 & 15) * 4;
-      Mx[(i + 0) * SA_LD + j] = q[it].x;
-      Mx[(i + 1) * SA_LD + j] = q[it].y;
-      Mx[(i + 2) * SA_LD + j] = q[it].z;
-      Mx[(i + 3) * SA_LD + j] = q[it].w;
-    }
+  for (int ch = 0; ch < SA_N / 32; ++ch)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fa[ch][i] = fb[(32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+  float g = tokfeat[(long long)b * SA_T + tid];
+
+  SA_CLOCK(1);      // loads issued
+  // ---- scores transposed into LDS: Mx[i][j] = scores[b][j][i]; dustbin row i = m ----
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int e4 = tid + 256 * it;
+    const int j = e4 >> 4, i = (e4 & 15) * 4;
+    Mx[(i + 0) * SA_LD + j] = q[it].x;
+    Mx[(i + 1) * SA_LD + j] = q[it].y;
+    Mx[(i + 2) * SA_LD + j] = q[it].z;
+    Mx[(i + 3) * SA_LD + j] = q[it].w;
   }
   Mx[SA_M * SA_LD + tid] = dustbin;
-  v[tid] = 0.f;
-  __syncthreads();
+  be[tid] = 1.f;
+  // second feature slab: requested now (the score registers are free again), added once K is computed
+  float fa2[NSLAB == 2 ? SA_N / 32 : 1][16];
+  if constexpr (NSLAB == 2) {
+    const float* fb2 = fb + slab_rows * SA_L;
+#pragma unroll
+    for (int ch = 0; ch < SA_N / 32; ++ch)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fa2[ch][i] = fb2[(32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+  }
+  lds_barrier();
 
-  const float log_nm = logf((float)(SA_N + SA_M));
-  const float log_a = -log_nm;
-  const float log_a_dust = logf((float)(SA_N - SA_M)) - log_nm;
-  const float log_b = -log_nm;
-
-  // The score matrix does not change across iterations (only u and v do): every thread keeps its operands of
-  // both half-steps in registers — its column (65 values) and its 16 entries of each of its 5 rows — so the
-  // iterations touch LDS only for u and v.  (One wave per SIMD: the 512-register budget is free anyway.)
+  SA_CLOCK(2);      // scores arrived and staged
+  // every thread keeps its operands of both half-steps in registers: its column (65 values) and its 16 entries of each
+  // of its 5 rows (one 16-lane group per matrix row, 16 rows in flight per workgroup)
   const int grp = tid >> 4, l16 = tid & 15;
   float mrow[5][16], mcol[SA_M + 1];
 #pragma unroll
@@ -110,122 +164,121 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   }
 #pragma unroll
   for (int i = 0; i <= SA_M; ++i) mcol[i] = Mx[i * SA_LD + tid];
-
-  for (int it = 0; it < iters; ++it) {
-    // u_i = log_a_i - LSE_j(M_ij + v_j): one 16-lane row group per matrix row (16 rows of the
-    // matrix in flight per workgroup), 16 columns per lane, DPP-only reductions.
-    {
-      float vv[16];
+  // row maxima r_i, then K = exp(M - r) in both register copies
 #pragma unroll
-      for (int c = 0; c < 16; ++c) vv[c] = v[l16 + 16 * c];
+  for (int p5 = 0; p5 < 5; ++p5) {
+    float mx = mrow[p5][0];
 #pragma unroll
-      for (int p5 = 0; p5 < 5; ++p5) {
-        const int i = 16 * p5 + grp;
-        float x[16];
-        float mx = -INFINITY;
+    for (int c = 1; c < 16; ++c) mx = fmaxf(mx, mrow[p5][c]);
+    mx = row16_max(mx);
+    const int i = 16 * p5 + grp;
+    if (l16 == 0 && i <= SA_M) al[i] = mx;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          x[c] = mrow[p5][c] + vv[c];
-          mx = fmaxf(mx, x[c]);
-        }
-        mx = row16_max(mx);
-        float sx = 0.f;
+    for (int c = 0; c < 16; ++c) mrow[p5][c] = __expf(mrow[p5][c] - mx);
+  }
+  lds_barrier();                                       // (also: every thread is done reading Mx)
+  // per-row values (row maxima here, alpha below) reach a thread's column loop as ONE LDS read per lane + v_readlane:
+  // 65 broadcast ds_reads, which the compiler serialises behind s_waitcnt one by one under this register pressure,
+  // cost 1.5 us per loop (phase clocks, scripts/sinkhorn_phases.py)
+  {
+    const float r_lane = al[lane], r_dust = al[SA_M];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) sx += __expf(x[c] - mx);
-        sx = row16_sum(sx);
-        if (l16 == 0 && i <= SA_M) u[i] = (i == SA_M ? log_a_dust : log_a) - (mx + __logf(sx));
-      }
-    }
-    __syncthreads();
-    // v_j = log_b - LSE_i(M_ij + u_i): thread per column
-    {
-      float x[SA_M + 1];
-      float mx = -INFINITY;
+    for (int i = 0; i < SA_M; ++i) mcol[i] = __expf(mcol[i] - lane_bcast(r_lane, i));
+    mcol[SA_M] = __expf(mcol[SA_M] - r_dust);
+  }
+  lds_barrier();                                       // al[] is about to be rewritten as alpha
+  if constexpr (NSLAB == 2) {
 #pragma unroll
-      for (int i = 0; i <= SA_M; ++i) { x[i] = mcol[i] + u[i]; mx = fmaxf(mx, x[i]); }
-      float sx = 0.f;
+    for (int ch = 0; ch < SA_N / 32; ++ch)
 #pragma unroll
-      for (int i = 0; i <= SA_M; ++i) sx += __expf(x[i] - mx);
-      v[tid] = log_b - (mx + __logf(sx));
-    }
-    __syncthreads();
+      for (int i = 0; i < 16; ++i) fa[ch][i] += fa2[ch][i];
   }
 
-  // ---- P = exp(M + u + v - norm), norm = -log(n+m); dustbin row dropped.  Stored as two bf16 planes
-  // (hi = bf16(P), lo = bf16(P - hi)) for the aggregation below. ----
+  SA_CLOCK(3);      // K in registers (and, NSLAB = 2, both feature slabs arrived)
+  const float inv_nm = 1.f / (float)(SA_N + SA_M);
+  const float a_reg = inv_nm, a_dust = (float)(SA_N - SA_M) * inv_nm, b_col = inv_nm;
+  for (int it = 0; it < iters; ++it) {
+    {                                                  // alpha_i = a_i / sum_j K_ij beta_j
+      float bv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) bv[c] = be[l16 + 16 * c];
+#pragma unroll
+      for (int p5 = 0; p5 < 5; ++p5) {
+        float sx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sx = fmaf(mrow[p5][c], bv[c], sx);
+        sx = row16_sum(sx);
+        const int i = 16 * p5 + grp;
+        if (l16 == 0 && i <= SA_M) al[i] = (i == SA_M ? a_dust : a_reg) / sx;
+      }
+    }
+    lds_barrier();  
+    {                                                  // beta_j = b_j / sum_i K_ij alpha_i
+      const float a_lane = al[lane];
+      float s0 = mcol[SA_M] * al[SA_M], s1 = 0.f;      // two chains: half the dependent-FMA latency
+#pragma unroll
+      for (int i = 0; i < SA_M; i += 2) {
+        s0 = fmaf(mcol[i], lane_bcast(a_lane, i), s0);
+        s1 = fmaf(mcol[i + 1], lane_bcast(a_lane, i + 1), s1);
+      }
+      be[tid] = b_col / (s0 + s1);
+    }
+    lds_barrier();
+  }
+
+  SA_CLOCK(4);      // iterations done
+  // ---- P = K alpha beta (n + m); dustbin row dropped.  Two bf16 planes (hi = bf16(P), lo = bf16(P - hi)) over the
+  // LDS of the score matrix (nobody reads Mx after the barrier above the iterations). ----
   {
     const int j = tid;
-    const float vj = v[j] + log_nm;
+    const float bj = be[j] * (float)(SA_N + SA_M);
+    const float a_lane = al[lane];
 #pragma unroll
     for (int i = 0; i < SA_M; ++i) {
-      const float pv = __expf(mcol[i] + u[i] + vj);
+      const float pv = mcol[i] * lane_bcast(a_lane, i) * bj;
       const __bf16 h = (__bf16)pv;
       const __bf16 l = (__bf16)(pv - (float)h);
       Phi[i * SA_PLD + j] = __builtin_bit_cast(uint16_t, h);
       Plo[i * SA_PLD + j] = __builtin_bit_cast(uint16_t, l);
     }
   }
-  __syncthreads();
+  lds_barrier();
 
+  SA_CLOCK(5);      // P planes in LDS
   // ---- V[l][m] = sum_j F[j][l] * P[m][j] on the bf16 matrix pipe at f32 accuracy ----
-  // The exact-f32 MFMA (v_mfma_f32_32x32x2_f32) needs 16.4k cycles per SIMD for this 4.2 MFLOP product — it was
-  // the longest phase of the kernel.  With F and P each split into two bf16 terms (2^-17 relative), the product
-  // is four v_mfma_f32_32x32x16_bf16 with exact products and f32 accumulation: 4.1k cycles, error <= 2^-16 per
-  // product (~1e-8 absolute on descriptor entries of 1e-2; tolerance 1e-4).
+  // F and P each split into two bf16 terms (2^-17 relative): three v_mfma_f32_32x32x16_bf16 (hi*hi, hi*lo, lo*hi) with exact
+  // products and f32 accumulation, error <= 2^-16 per product (~1e-8 absolute on descriptor entries of 1e-2; tolerance 1e-4).
   // 32x32x16 operand maps: A[i = lane&31][k = 8*(lane>>5) + e], B[k = 8*(lane>>5) + e][j = lane&31].
   // Wave w owns cluster-dim rows l0 = 32w .. 32w+31 and both 32-cluster column blocks.
-  const float* fb = feats + (long long)b * SA_N * SA_L;
-  const int l0 = 32 * wave;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
-  const int kh = lane >> 5, li = lane & 31;
-  // F comes straight from L2 (32 KB per wave, each value used once): 2 k-steps (32 tokens) per chunk,
-  // the next chunk's 16 loads are in flight while the current chunk's 16 MFMAs run.
-  float a_cur[16], a_nxt[16], b_nxt[16];
-  const float* fb2 = fb + slab_rows * SA_L;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) a_cur[i] = fb[(16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
-  if constexpr (NSLAB == 2) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_cur[i] += fb2[(16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
-  }
 #pragma unroll
   for (int ch = 0; ch < SA_N / 32; ++ch) {
-    if (ch + 1 < SA_N / 32) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) a_nxt[i] = fb[(32 * (ch + 1) + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
-      if constexpr (NSLAB == 2) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) b_nxt[i] = fb2[(32 * (ch + 1) + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
-      }
-    }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       bf16x8 fh, fl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        fh[e] = (__bf16)a_cur[8 * st + e];
-        fl[e] = (__bf16)(a_cur[8 * st + e] - (float)fh[e]);
+        fh[e] = (__bf16)fa[ch][8 * st + e];
+        fl[e] = (__bf16)(fa[ch][8 * st + e] - (float)fh[e]);
       }
       const int j0 = 32 * ch + 16 * st + 8 * kh;
       const bf16x8 p0h = *reinterpret_cast<const bf16x8*>(Phi + li * SA_PLD + j0);
       const bf16x8 p0l = *reinterpret_cast<const bf16x8*>(Plo + li * SA_PLD + j0);
       const bf16x8 p1h = *reinterpret_cast<const bf16x8*>(Phi + (32 + li) * SA_PLD + j0);
       const bf16x8 p1l = *reinterpret_cast<const bf16x8*>(Plo + (32 + li) * SA_PLD + j0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p0l, acc0, 0, 0, 0);     // smallest terms first
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p1l, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p0h, acc0, 0, 0, 0);
+      // (the lo x lo term is 2^-34 of the product: below f32 resolution, dropped)
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p0h, acc0, 0, 0, 0);     // smallest terms first
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, p1h, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p0l, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p1l, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p0h, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, p1h, acc1, 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a_cur[i] = NSLAB == 2 ? a_nxt[i] + b_nxt[i] : a_nxt[i];
   }
 
+  SA_CLOCK(6);      // aggregation MFMAs issued (features arrived)
   // ---- per-cluster L2 norm over l (F.normalize dim=1, eps 1e-12) ----
   {
     float s0 = 0.f, s1 = 0.f;
@@ -247,7 +300,6 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   }
 
   // ---- token vector: F.normalize(g) ----
-  float g = tokfeat[(long long)b * SA_T + tid];
   const float gn = fmaxf(sqrtf(block_sum_256(g * g, red)), 1e-12f);
   g = g / gn;
 
@@ -255,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   const float tot = block_sum_256(part + g * g, red);
   const float gden = fmaxf(sqrtf(tot), 1e-12f);
 
+  SA_CLOCK(7);      // norms done
   float* ob = out_f32 + (long long)b * D_OUT;
   uint16_t* obh = out_bf16 ? out_bf16 + (long long)b * D_OUT : nullptr;
   {
@@ -272,9 +325,10 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     ob[base + 32 + li] = o1;
     if (obh) { obh[base + li] = f32_to_bf16_bits(o0); obh[base + 32 + li] = f32_to_bf16_bits(o1); }
   }
+  SA_CLOCK(8);
 }
 
-constexpr size_t SINKHORN_LDS = SA_PLANES_OFF + 2 * (size_t)SA_M * SA_PLD * sizeof(uint16_t);
+constexpr size_t SINKHORN_LDS = SA_SMALL_OFF + (68 + SA_N + 4 * SA_M + 4) * sizeof(float);
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
@@ -371,7 +425,7 @@ static int salad_stage_mlps(const SaladArgs& a, const uint16_t* patch, long long
   const int rows = a.B * a.n, hidden = a.hidden;
   if (salad_slabs(a.n, a.C, a.m, a.l, hidden) == 2)
     return launch_salad_mlps_fused(patch, a.C, a.n, patch_img_stride, w->w1_sc, w->b1_sc, w->w2_s, w->b2_s, w->w2_c, w->b2_c,
-                                   S, F, rows, a.C, hidden, a.m, a.l, stream);
+                                   S, F, rows, a.C, hidden, a.m, a.l, stream, w->w2_s_frag, w->w2_c_frag);
   // unfused: layer 1 on the 256 x 256-tile kernel (34 of SALAD's 38 GFLOP; B tiles x 4 = one full wave of workgroups at
   // B = 64), hidden activations through HBM as bf16, the two second layers as one grouped launch
   const GemmProblem l1_sc{patch, a.C, a.n, patch_img_stride, w->w1_sc, a.C, w->b1_sc, 1, H, 2 * hidden, 1, rows, 2 * hidden, a.C, 0, 0};
@@ -411,6 +465,13 @@ extern "C" int vpr_salad_sinkhorn_aggregate(const float* scores, const float* fe
   return launch_sinkhorn_aggregate(scores, feats, tokfeat, B, n, m, l, t, dustbin, sinkhorn_iters,
                                    out_f32, out_bf16, static_cast<hipStream_t>(stream));
 }
+
+#ifdef VPR_ABLATION
+// timing-only build: where the phase clocks of sinkhorn_aggregate_kernel go ([B][16] int64 on the device; null = off)
+extern "C" int vpr_salad_sinkhorn_set_clocks(long long* clocks) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sinkhorn_clocks), &clocks, sizeof(clocks)) == hipSuccess ? VPR_OK : VPR_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int vpr_salad_stage_token(const uint16_t* cls_tokens, long long cls_stride, int B, int n, int C,
                                      const vpr_salad_weights* w, int m, int l, int t, int hidden,

@@ -14,6 +14,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int WAVE = 64;
 
+// 100 MHz constant clock, read where the statement stands (volatile asm with a memory clobber: the compiler may not move
+// it across the surrounding code) — phase clocks of the timing-only build.
+__device__ __forceinline__ long long vpr_clock_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return (long long)t;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
@@ -22,6 +30,14 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t v) {
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(uint16_t, h);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() compiles to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier,
+// i.e. it also drains every global load the wave has in flight; a kernel that wants its global loads to keep flying
+// across barriers (the compiler still waits for each loaded register before its first use) uses this one.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

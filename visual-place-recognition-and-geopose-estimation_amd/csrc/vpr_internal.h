@@ -31,7 +31,8 @@ int launch_gemm256(const GemmProblem& problem, hipStream_t stream);   // gemm256
 // hidden / 256 partial-sum slabs of [M][m] / [M][l] f32 (slab 0 carries the bias), to be added in slab order
 int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long long group_stride, const uint16_t* W1, const float* b1,
                             const uint16_t* W2s, const float* b2s, const uint16_t* W2c, const float* b2c,
-                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream);
+                            float* S, float* F, int M, int C, int hidden, int m, int l, hipStream_t stream,
+                            const uint16_t* W2s_frag = nullptr, const uint16_t* W2c_frag = nullptr);
 // gemm256.hip, fp8 form: e4m3 operands with per-row scales, f32 out (kNN score tile of a >= 384-query gathered batch)
 int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const uint8_t* W, int ldw, const float* w_scale,
                        float* C, int ldc, int M, int N, int K, hipStream_t stream, int ksplit = 1, long long slab_stride = 0);

@@ -115,7 +115,42 @@ class SaladWeights:
         return C, hidden, m, l, t
 
     def c_struct(self) -> _lib.SaladWeightsC:
-        return _lib.SaladWeightsC(*[getattr(self, n).data_ptr() for n, _ in _lib.SaladWeightsC._fields_])
+        fs, fc = _salad_w2_fragments(self)
+        ptrs = [getattr(self, n).data_ptr() for n, _ in _lib.SaladWeightsC._fields_[:10]]
+        return _lib.SaladWeightsC(*ptrs, fs.data_ptr() if fs is not None else None, fc.data_ptr() if fc is not None else None)
+
+
+_SALAD_FRAGS: dict = {}
+salad_use_fragments = True      # False: hand the C ABI null *_frag pointers (the kernel then reads W2 row-major; tests / A/B)
+
+
+def _salad_w2_fragments(w: "SaladWeights"):
+    """(w2_s, w2_c) in MFMA fragment order (vpr_salad_pack_w2_fragments), packed once per (storage, version) like the pose
+    head's planes: entries keep their source tensors alive (no recycled-address hits) and are pinned once a HIP graph
+    has been captured on them."""
+    out = []
+    if not salad_use_fragments:
+        return None, None
+    for src in (w.w2_s, w.w2_c):
+        n_out, hidden = src.shape
+        if src.dtype != torch.bfloat16 or not src.is_cuda or n_out % 16 or hidden % 256:
+            out.append(None)
+            continue
+        key = (src.data_ptr(), src._version, n_out, hidden, str(src.device))
+        hit = _SALAD_FRAGS.get(key)
+        if hit is None:
+            while len(_SALAD_FRAGS) >= 16:
+                old = _SALAD_FRAGS.pop(next(iter(_SALAD_FRAGS)))
+                if old[2]:
+                    _GRAPH_PINNED.append(old)
+            frag = torch.empty_like(src)
+            st = _lib.lib().vpr_salad_pack_w2_fragments(_ptr(src), n_out, hidden, _ptr(frag), _stream())
+            _lib.check(st, "vpr_salad_pack_w2_fragments")
+            hit = _SALAD_FRAGS[key] = [frag, src, False]
+        if not hit[2] and capturing():
+            hit[2] = True
+        out.append(hit[0])
+    return out[0], out[1]
 
 
 def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int = 3,
@@ -203,6 +238,9 @@ class SaladWeightsF32(SaladWeights):
         for n in ("b1_sc", "b2_s", "b2_c", "b1_t", "b2_t"):
             _need(getattr(self, n), torch.float32, n, 1)
         return self._shapes()
+
+    def c_struct(self) -> _lib.SaladWeightsF32C:
+        return _lib.SaladWeightsF32C(*[getattr(self, n).data_ptr() for n, _ in _lib.SaladWeightsF32C._fields_])
 
 
 def salad_aggregate_f32(tokens, w: SaladWeightsF32, sinkhorn_iters: int = 3,
