@@ -188,3 +188,28 @@ def test_sinkhorn_exp_domain_survives_extreme_scores(dev, case):
     err = (out.cpu().double() - ref).abs().max().item()
     print(f"{case}: max abs err {err:.2e}")
     assert err < 5e-6
+
+
+def test_token_mlp_on_the_backbone_cls_stream_is_bit_identical(dev):
+    """DinoV2Salad.features runs SALAD's token MLP on the backbone's cls-row side stream (backbone.cls_tail_hook ->
+    ops.salad_stage_token) and the aggregation then runs stages M + A only (token_done): same kernels on the same bits as
+    the in-stream one-call form; several batches in a row (the workspace is re-used across steps)."""
+    from vpr_amd.modules import DinoV2Salad
+    torch.manual_seed(5)
+    ext = DinoV2Salad("vit_small").to(dev).to(torch.bfloat16).eval()
+    for p in ext.aggregator.parameters():
+        if p.dim() > 0:
+            torch.nn.init.normal_(p, std=0.05)
+    ext.backbone.fold_layerscale()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for B in (8, 8, 3, 8):
+        x = torch.randn(B, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
+        ext.token_on_cls_stream = True
+        t = ext.backbone(x, split=True)
+        assert t.token_ready is False                                   # no hook installed outside features()
+        d1, d1h = ext.features(x, want_bf16=True)
+        ext.token_on_cls_stream = False
+        d0, d0h = ext.features(x, want_bf16=True)
+        torch.cuda.synchronize()
+        assert torch.equal(d0, d1) and torch.equal(d0h, d1h)
+    ext.token_on_cls_stream = True

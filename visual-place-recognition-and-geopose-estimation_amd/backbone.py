@@ -50,9 +50,11 @@ def _ln(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
 
 class SplitTokens(NamedTuple):
     """Final-norm tokens as the HIP backbone path holds them: patch [B, n, C] and cls [B, C], both
-    contiguous (vpr_salad_aggregate_split consumes the pair without a copy)."""
+    contiguous (vpr_salad_aggregate_split consumes the pair without a copy).  token_ready: the backbone's cls-row
+    stream already ran `cls_tail_hook` on these cls rows (the SALAD token MLP), ordered before the current stream."""
     patch: torch.Tensor
     cls: torch.Tensor
+    token_ready: bool = False
 
     def joined(self) -> torch.Tensor:
         """[B, 1+n, C], cls first (the reference / torch.hub layout)."""
@@ -259,7 +261,7 @@ class DinoV2(nn.Module):
         qkv = torch.empty((M, C3), dtype=bf, device=dev)
         torch.addmm(blocks[0].qkv.bias, hp, blocks[0].qkv.weight.t(), out=qkv[:Mp])
         ops.skinny_linear_bf16(h[Mp:], blocks[0].qkv.weight, blocks[0].qkv.bias, qkv[Mp:], 0)
-        cls_out = None
+        cls_out, hooked = None, False
         for i, blk in enumerate(blocks):
             last = i + 1 == len(blocks)
             nb = blocks[i + 1] if not last else None
@@ -280,6 +282,9 @@ class DinoV2(nn.Module):
                     ops.skinny_linear_bf16(hc2, nb.qkv.weight, nb.qkv.bias, qkv_next[Mp:], 0)
                 else:
                     cls_out = hc2
+                    if self.cls_tail_hook is not None:     # e.g. SALAD's token MLP: needs the cls rows only, rides on this stream
+                        self.cls_tail_hook(cls_out, main.cuda_stream)
+                        hooked = True
                 join = torch.cuda.Event()
                 join.record(side)
             xp.addmm_(att[:Mp], blk.proj.weight.t())
@@ -291,7 +296,11 @@ class DinoV2(nn.Module):
                 torch.addmm(nb.qkv.bias, hp, nb.qkv.weight.t(), out=qkv_next[:Mp])
             main.wait_event(join)          # the side chain finished ~0.3 ms ago: satisfied on arrival
             qkv = qkv_next                 # (att stayed referenced up to here)
-        return SplitTokens(hp.view(B, n, C), cls_out)
+        return SplitTokens(hp.view(B, n, C), cls_out, hooked)
+
+    # optional callable(cls_rows [B, C] bf16, raw handle of the main stream): run on the cls-row side stream right after the
+    # final LayerNorm of the cls rows, before that stream is joined (modules.DinoV2Salad installs SALAD's token MLP here)
+    cls_tail_hook = None
 
     def _raw_tokens(self, M: int, Mp: int, C: int, dev: torch.device) -> torch.Tensor:
         bufs = self.__dict__.setdefault("_raw_bufs", {})     # per (device, stream, shape): two streams never share it

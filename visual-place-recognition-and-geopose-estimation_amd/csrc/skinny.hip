@@ -13,7 +13,8 @@
 
 namespace vpr {
 
-enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2, SK_BIAS_RELU = 3, SK_BIAS_GELU_ERF = 4 };
+enum { SK_BIAS = 0, SK_BIAS_GELU = 1, SK_ACCUMULATE = 2, SK_BIAS_RELU = 3, SK_BIAS_GELU_ERF = 4,
+       SK_BIAS_F32 = 5 /* out is float*, ldo in floats: SALAD token features */ };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2 u): the form hipBLASLt's epilogue uses
@@ -73,6 +74,17 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(
   }
   const int m = m0 + wave * 16 + r, n = n0 + 4 * g;
   const bool live = m < M && n < N;
+  if (mode == SK_BIAS_F32) {                    // f32 output, bias only
+    if (live) {
+      float* of = reinterpret_cast<float*>(out) + (long long)m * ldo + n;
+      for (int e = 0; e < 4 && n + e < N; ++e) {
+        float b;
+        if constexpr (sizeof(BiasT) == 2) b = bf16_bits_to_f32((uint16_t)bias[n + e]); else b = bias[n + e];
+        of[e] = s[e] + b;
+      }
+    }
+    return;
+  }
   uint16_t* op = out + (long long)min(m, M - 1) * ldo + min(n, N - 1);
   float v[4] = {s[0], s[1], s[2], s[3]};
   uint16_t ob[4] = {0, 0, 0, 0};
@@ -131,7 +143,7 @@ int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw
                          int bias_is_bf16, int mode, uint16_t* out, int ldo, int M, int N, int K,
                          const float* stats_bias, float* row_stats, void* stream) {
   if (row_stats != nullptr && (N % 16)) return VPR_ERR_UNSUPPORTED;
-  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 4) return VPR_ERR_INVALID_ARG;
+  if (!in || !W || !out || M < 0 || N <= 0 || K <= 0 || mode < 0 || mode > 5) return VPR_ERR_INVALID_ARG;
   if (mode != SK_ACCUMULATE && !bias) return VPR_ERR_INVALID_ARG;
   if (M == 0) return VPR_OK;
   if ((K % 32) || (ldi % 8) || (ldw % 8) || ldi < K || ldw < K || ldo < N) return VPR_ERR_UNSUPPORTED;

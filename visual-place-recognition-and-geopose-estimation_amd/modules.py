@@ -79,6 +79,13 @@ class SaladAggregator(nn.Module):
             dustbin=float(self.dust_bin.detach().cpu()))
         return self._packed_f32
 
+    def token_stage(self, cls_rows: torch.Tensor, owner_raw_stream: int) -> None:
+        """The token MLP of these cls rows on the current stream, into the workspace of `owner_raw_stream`
+        (backbone.DinoV2.cls_tail_hook: the backbone's cls-row stream has the cls tokens ~0.3 ms before the main stream has
+        the patch tokens, so the stage costs the step nothing)."""
+        w = self._packed or self.pack()
+        ops.salad_stage_token(cls_rows, w, 256, owner_raw_stream)
+
     @torch.no_grad()
     def forward(self, tokens, want_bf16: bool = False):
         """tokens [B, 1+n, C] (cls first) or a backbone.SplitTokens pair -> descriptor [B, 8448] f32 (and a bf16 copy).
@@ -95,7 +102,8 @@ class SaladAggregator(nn.Module):
             return (desc, desc16) if want_bf16 else desc
         w = self._packed or self.pack()
         if isinstance(tokens, SplitTokens):
-            desc, desc16 = _vpr.salad_aggregate_split(tokens.patch, tokens.cls, torch_ops.weight_list(w), w.dustbin, 3)
+            desc, desc16 = _vpr.salad_aggregate_split(tokens.patch, tokens.cls, torch_ops.weight_list(w), w.dustbin, 3,
+                                                      bool(tokens.token_ready))
         else:
             desc, desc16 = _vpr.salad_aggregate(tokens, torch_ops.weight_list(w), w.dustbin, 3)
         return (desc, desc16) if want_bf16 else desc
@@ -109,6 +117,8 @@ class DinoV2Salad(nn.Module):
         self.backbone = DinoV2(arch)
         self.aggregator = SaladAggregator(self.backbone.embed_dim)
 
+    token_on_cls_stream = True      # SALAD's token MLP rides on the backbone's cls-row stream (bit-identical; A/B switch)
+
     @torch.no_grad()
     def tokens(self, x: torch.Tensor) -> torch.Tensor:
         """Final-norm tokens [B, 1+n, C] bf16, cls first (the hub model's layout)."""
@@ -116,13 +126,26 @@ class DinoV2Salad(nn.Module):
         return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
 
     @torch.no_grad()
-    def features(self, x: torch.Tensor, want_bf16: bool = False):
+    def features(self, x: torch.Tensor, want_bf16: bool = False, events: Optional[list] = None):
         """images -> descriptor (and its bf16 copy): backbone tokens stay in the layout the backbone
-        computed them in (SplitTokens on the HIP path), no re-layout copy before SALAD."""
-        t = self.backbone(x, split=True)
+        computed them in (SplitTokens on the HIP path), no re-layout copy before SALAD.
+        events: a list -> a (start, end) pair of timing events around the aggregation on the current stream is appended
+        (bench.py: the SALAD stage as the step runs it, token MLP on the backbone's cls-row stream)."""
+        self.backbone.cls_tail_hook = self.aggregator.token_stage if self.token_on_cls_stream else None
+        try:
+            t = self.backbone(x, split=True)
+        finally:
+            self.backbone.cls_tail_hook = None
         if t.patch.dtype not in (torch.bfloat16, torch.float32):
             t = SplitTokens(t.patch.to(torch.bfloat16), t.cls.to(torch.bfloat16))
-        return self.aggregator(t, want_bf16=want_bf16)          # f32 tokens (an f32 model) take the f32-accurate aggregation
+        if events is None:
+            return self.aggregator(t, want_bf16=want_bf16)      # f32 tokens (an f32 model) take the f32-accurate aggregation
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = self.aggregator(t, want_bf16=want_bf16)
+        e1.record()
+        events.append((e0, e1))
+        return out
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> torch.Tensor:

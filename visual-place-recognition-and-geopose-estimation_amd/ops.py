@@ -53,12 +53,13 @@ def capturing() -> bool:
 _GRAPH_PINNED: list = []       # buffers a captured graph addresses, kept alive when their cache entry is replaced
 
 
-def workspace(name: str, nbytes: int, device: torch.device) -> torch.Tensor:
+def workspace(name: str, nbytes: int, device: torch.device, stream_key: Optional[int] = None) -> torch.Tensor:
     """Cached byte buffer per (device, stream, name); grows, never shrinks.  Keyed by the current stream so that
     two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory.  A buffer
-    handed out during graph capture is never freed (a later, larger request gets a new one; the old stays pinned)."""
+    handed out during graph capture is never freed (a later, larger request gets a new one; the old stays pinned).
+    stream_key: raw handle of the stream that OWNS the buffer when the caller is working for it from a helper stream."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _raw_stream(idx), name)
+    key = (idx, _raw_stream(idx) if stream_key is None else stream_key, name)
     ent = _WORKSPACES.get(key)
     if ent is None or ent[0].numel() < nbytes:
         if ent is not None and ent[1]:
@@ -175,7 +176,6 @@ def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int =
 
 
 _SALAD_SIDE: dict = {}
-salad_overlap_token_mlp = True      # module switch (A/B: bench.py --no-salad-overlap)
 
 
 def _salad_side_stream(device: torch.device, main_raw: int) -> torch.cuda.Stream:
@@ -186,12 +186,32 @@ def _salad_side_stream(device: torch.device, main_raw: int) -> torch.cuda.Stream
     return s
 
 
+def salad_stage_token(cls: torch.Tensor, w: SaladWeights, n: int, owner_raw_stream: int) -> None:
+    """Stage T of the aggregation on its own (vpr_salad_stage_token): token MLP of the B cls rows on the CURRENT stream,
+    result left in the SALAD workspace that belongs to stream `owner_raw_stream` (the stream that will run
+    salad_aggregate_split(..., token_done=True) for the same batch, ordered after this call by the caller).  The DINOv2
+    backbone calls it from its cls-row side stream, where the cls tokens are final ~0.3 ms before the patch tokens."""
+    _need(cls, torch.bfloat16, "cls", 2)
+    C, hidden, m, l, t = w.validate()
+    B, Ct = cls.shape
+    if Ct != C:
+        raise RuntimeError(f"cls {tuple(cls.shape)} does not match weights with C={C}")
+    L = _lib.lib()
+    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), cls.device, stream_key=owner_raw_stream)
+    cw = w.c_struct()
+    st = L.vpr_salad_stage_token(_ptr(cls), C, B, n, C, ctypes.byref(cw), m, l, t, hidden, _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_salad_stage_token")
+
+
 def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeights, sinkhorn_iters: int = 3,
-                          want_bf16: bool = True, overlap: Optional[bool] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                          want_bf16: bool = True, overlap: Optional[bool] = None,
+                          token_done: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """patch [B, n, C] bf16 + cls [B, C] bf16 -> (descriptor f32 [B, t+l*m], bf16 copy or None).
-    overlap (default: on, off while a HIP graph is being captured): the aggregation runs as its three stages with the token
-    MLP (64 cls rows: two 5 us weight streams) on a side stream beside the all-CU score / cluster GEMM, joined before the
-    Sinkhorn stage — same kernels, same workspace, bit-identical result to the one-call form."""
+    token_done: salad_stage_token already ran for these cls rows (and is ordered before this call): stages M and A only.
+    overlap=True: the aggregation runs as its three stages with the token MLP (64 cls rows: two 4 us weight streams) on a
+    side stream beside the all-CU score / cluster GEMM, joined before the Sinkhorn stage — same kernels, same workspace,
+    bit-identical result to the one-call form.  Off by default: one fork + join between two HIP streams costs ~25 us here;
+    the pipeline hides the token MLP for free by running it on the backbone's cls-row stream (salad_stage_token)."""
     _need(patch, torch.bfloat16, "patch", 3)
     _need(cls, torch.bfloat16, "cls", 2)
     C, hidden, m, l, t = w.validate()
@@ -203,8 +223,16 @@ def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeight
     out = torch.empty((B, t + l * m), dtype=torch.float32, device=patch.device)
     out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=patch.device) if want_bf16 else None
     cw = w.c_struct()
+    if token_done:
+        raw = _stream()
+        st = L.vpr_salad_stage_mlps(_ptr(patch), n * C, B, n, C, ctypes.byref(cw), m, l, t, hidden, _ptr(ws), ws.numel(), raw)
+        _lib.check(st, "vpr_salad_stage_mlps")
+        st = L.vpr_salad_stage_aggregate(B, n, C, float(w.dustbin), m, l, t, hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16),
+                                         _ptr(ws), ws.numel(), raw)
+        _lib.check(st, "vpr_salad_stage_aggregate")
+        return out, out16
     if overlap is None:
-        overlap = salad_overlap_token_mlp and not capturing()
+        overlap = False     # measured (scripts/salad_ab.py): the fork + join of a side stream costs more than the 10 us it hides
     if not overlap:
         st = L.vpr_salad_aggregate_split(_ptr(patch), _ptr(cls), B, n, C, ctypes.byref(cw), float(w.dustbin), m, l, t,
                                          hidden, int(sinkhorn_iters), _ptr(out), _ptr(out16), _ptr(ws), ws.numel(), _stream())

@@ -35,6 +35,7 @@ class VPRGeoPosePipeline:
         self.graph_retrieval = graph_retrieval
         self._graphed = {}
         self.knn_events = None     # optional list collecting (start, end) events of the score kernel (graph: of the replay)
+        self.salad_events = None   # optional list collecting (start, end) events around the SALAD aggregation of every step
         # The pose head needs only the descriptor; the retrieval leg (two collectives with launch-latency gaps between
         # them when the gallery is sharded) runs beside it: head on a side stream, joined at the end of the step.
         self.overlap_head = gallery.collective if overlap_head is None else overlap_head
@@ -49,7 +50,7 @@ class VPRGeoPosePipeline:
 
     @torch.no_grad()
     def step(self, images: torch.Tensor) -> StepOutput:
-        desc, desc16 = self.extractor.features(images, want_bf16=True)
+        desc, desc16 = self.extractor.features(images, want_bf16=True, events=self.salad_events)
         g = self.gallery
         pose = None
         if self.overlap_head:

@@ -59,14 +59,16 @@ def _(tokens, weights, dustbin, sinkhorn_iters):
 
 @torch.library.custom_op("vpr::salad_aggregate_split", mutates_args=())
 def salad_aggregate_split(patch: Tensor, cls: Tensor, weights: List[Tensor], dustbin: float,
-                          sinkhorn_iters: int) -> Tuple[Tensor, Tensor]:
-    """patch [B, n, C] bf16 + cls [B, C] bf16 (the layout the HIP backbone computes in).  vpr_salad_aggregate_split."""
-    out, out16 = ops.salad_aggregate_split(patch, cls, _weights(weights, dustbin), sinkhorn_iters, True)
+                          sinkhorn_iters: int, token_done: bool = False) -> Tuple[Tensor, Tensor]:
+    """patch [B, n, C] bf16 + cls [B, C] bf16 (the layout the HIP backbone computes in).  vpr_salad_aggregate_split, or —
+    token_done: the token MLP of these cls rows already ran on the backbone's cls-row stream (ops.salad_stage_token) —
+    vpr_salad_stage_mlps + vpr_salad_stage_aggregate."""
+    out, out16 = ops.salad_aggregate_split(patch, cls, _weights(weights, dustbin), sinkhorn_iters, True, token_done=token_done)
     return out, out16
 
 
 @salad_aggregate_split.register_fake
-def _(patch, cls, weights, dustbin, sinkhorn_iters):
+def _(patch, cls, weights, dustbin, sinkhorn_iters, token_done=False):
     B, D = patch.shape[0], _desc_width(weights)
     return patch.new_empty((B, D), dtype=torch.float32), patch.new_empty((B, D), dtype=torch.bfloat16)
 
