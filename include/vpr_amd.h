@@ -314,6 +314,24 @@ int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const uint16_t* W
                         const float* W2, const float* b2, float* out, int B, int D, int hidden,
                         int n_out, int sincos_offset, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Single-launch form of the same head (round 3).  W1's planes in MFMA FRAGMENT order (vpr_pose_head_pack_w1_frag:
+ * plane[((nb * (D/32) + s) * 64 + lane) * 8 + e] = W1[nb*16 + (lane & 15)][s*32 + 8*(lane >> 4) + e] — a wave's weight
+ * load is then one contiguous 1 KB), and the split-K slabs finished inside the kernel by arrival counters: the workgroup
+ * that arrives last at a (hidden tile, batch tile) adds that tile's slabs in slice order, applies bias / ReLU / its
+ * columns of W2; the last of those per batch tile adds the second-layer partials in tile order, b2, the pair normalise.
+ * Same arithmetic and summation orders as vpr_pose_head_split: bitwise reproducible run to run.
+ * WORKSPACE CONTRACT: the first vpr_pose_head_fused_counter_bytes() bytes (4096, whatever the shape) hold the arrival
+ * counters; they must be ZERO before the first call on a buffer and are left zero by every call (memset once after
+ * allocation, never again); calls of different shapes may share a workspace.  Shapes with more than 1024 (hidden tile,
+ * batch tile) pairs return VPR_ERR_UNSUPPORTED (use vpr_pose_head_split).
+ * Requires D % 32 == 0, hidden % 16 == 0, 1 <= n_out <= 8, 16-byte aligned pointers. */
+size_t vpr_pose_head_fused_workspace_bytes(int B, int D, int hidden);
+size_t vpr_pose_head_fused_counter_bytes(int B, int D, int hidden);
+int vpr_pose_head_pack_w1_frag(const float* W1, int hidden, int D, uint16_t* hi, uint16_t* lo, void* stream);
+int vpr_pose_head_fused(const float* x, const uint16_t* W1_hi_frag, const uint16_t* W1_lo_frag, const float* b1,
+                        const float* W2, const float* b2, float* out, int B, int D, int hidden,
+                        int n_out, int sincos_offset, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh
  * Replaces: `outputs.pooler_output` + `self.regressor`  swin_transformer/swin_validation.py:43-46

@@ -1,37 +1,40 @@
-"""A/B of the pose head's split-K factor (VPR_POSE_KS) and timing of the Swin pooler head, one process, interleaved."""
+"""A/B of the pose head forms and of the split-K factor (VPR_POSE_KS), one process, interleaved: fused single-launch kernel
+vs two-launch split form, bench head shape (B = 64, D = 8448, hidden = 1024, n_out = 4) and the reference head (hidden 512)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vpr_amd import _lib, ops
+
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-B, D, H = 64, 8448, 1024
-x = torch.randn(B, D, device=dev, generator=g)
-W1 = torch.randn(H, D, device=dev, generator=g) * 0.01
-b1 = torch.zeros(H, device=dev)
-W2 = torch.randn(4, H, device=dev, generator=g) * 0.05
-b2 = torch.zeros(4, device=dev)
-def timeit(fn, n=20):
-    for _ in range(3): fn()
+
+
+def timeit(fn, iters=40, warm=5):
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-ks_list = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,11,16,22,24,33").split(",")]
-res = {k: [] for k in ks_list}
-for r in range(6):
-    for k in ks_list:
-        if k: _lib.tuning_set("VPR_POSE_KS", int(k))
-        else: _lib.tuning_set("VPR_POSE_KS", None)
-        t = timeit(lambda: ops.pose_head(x, W1, b1, W2, b2, 2))
-        res[k].append(t)
-for k in ks_list:
-    t = sorted(res[k])
-    print(f"VPR_POSE_KS={k:3d}: median {t[len(t)//2]:6.1f} us  min {t[0]:6.1f} us")
-for T in (49, 144):
-    xs = torch.randn(256, T, 1024, device=dev, generator=g).to(torch.bfloat16)
-    gm, bt = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
-    Wh, bh = torch.randn(4, 1024, device=dev, generator=g) * 0.03, torch.zeros(4, device=dev)
-    t = timeit(lambda: ops.ln_meanpool_head(xs, gm, bt, 1e-5, Wh, bh, 2, want_pooled=False))
-    print(f"ln_meanpool_head 256x{T}x1024 bf16: {t:6.1f} us = {xs.numel() * 2 / t / 1e6:6.0f} GB/s")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    return t[len(t) // 2], t[0]
+
+
+for hidden in (1024, 512):
+    B, D = 64, 8448
+    x = torch.nn.functional.normalize(torch.randn(B, D, device=dev, generator=g), dim=1)
+    W1 = torch.randn(hidden, D, device=dev, generator=g) * 0.01
+    b1 = torch.zeros(hidden, device=dev)
+    W2 = torch.randn(4, hidden, device=dev, generator=g) * 0.05
+    b2 = torch.zeros(4, device=dev)
+    by = (W1.numel() + W2.numel()) * 4 + x.numel() * 4
+    for ks in (None, 4, 8, 12, 16, 24, 32):
+        _lib.tuning_set("VPR_POSE_KS", ks)
+        row = f"hidden={hidden} KS={ks if ks else 'auto':>4}:"
+        for name, kw, var in (("frag+counters", dict(fused=True), 1), ("frag+epilogue", dict(fused=True), 2), ("rowmajor+epilogue", dict(fused=False), 0)):
+            _lib.tuning_set("VPR_POSE_VARIANT", var)
+            med, best = timeit(lambda: ops.pose_head(x, W1, b1, W2, b2, 2, **kw))
+            row += f"  {name} {med:6.1f} us ({by / med / 1e6 / 8000:.3f})"
+        _lib.tuning_set("VPR_POSE_VARIANT", None)
+        print(row)
+    _lib.tuning_set("VPR_POSE_KS", None)

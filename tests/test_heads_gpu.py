@@ -22,17 +22,22 @@ def _linear_init(out_f, in_f, g):
     (7, 768, 384, 2, 0),        # sin/cos MLP head, ragged batch
     (1, 64, 32, 1, -1),
 ])
-@pytest.mark.parametrize("split", [True, False])
-def test_mlp_head(dev, B, D, hidden, n_out, off, split):
-    """split=True: first layer as four bf16 MFMAs on (hi, lo) planes (default); False: exact-f32 MFMA.  Both must
-    sit far inside the 1e-4 tolerance: the split path's error budget is 2^-16 per product, ~1e-7 on the output."""
+@pytest.mark.parametrize("split", ["counters", "frag", True, False])
+def test_mlp_head(dev, tune, B, D, hidden, n_out, off, split):
+    """"counters": the single-launch kernel (fragment-order (hi, lo) planes, split-K finished by arrival counters);
+    "frag": the same kernel writing slabs only + an epilogue launch; True: the two-launch split form on row-major planes
+    (default); False: exact-f32 MFMA.  All must sit far inside the 1e-4 tolerance: the split paths' error budget is
+    2^-16 per product, ~1e-7 on the output."""
+    if split == "counters":
+        tune("VPR_POSE_VARIANT", 1)
     from vpr_amd import ops
     g = torch.Generator().manual_seed(B + D)
     x = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1) if D == 8448 else torch.randn(B, D, generator=g)
     W1, b1 = _linear_init(hidden, D, g)
     W2, b2 = _linear_init(n_out, hidden, g)
     ref = oheads.mlp_head(x, W1, b1, W2, b2, off)
-    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), off, split=split).cpu().double()
+    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), off, split=bool(split),
+                        fused=split in ("counters", "frag")).cpu().double()
     err = (out - ref).abs().max().item()
     print("mlp head err", err)
     assert err < TOL
@@ -60,6 +65,41 @@ def test_head_is_deterministic(dev):
     a = ops.pose_head(x, *args, 2)
     b = ops.pose_head(x, *args, 2)
     assert torch.equal(a, b)
+
+
+def test_fused_head_counters_survive_many_calls_and_shapes(dev, tune):
+    """vpr_pose_head_fused: the arrival counters at the head of the workspace are left zero by every call, so calls of
+    different shapes can share one workspace back to back (the wrapper zero-fills a workspace only when it allocates it);
+    every call is bitwise reproducible (fixed summation orders at both counter levels) and within TOL of the f64 oracle.
+    Ragged batches (rows of the last 64-row tile masked), hidden not a multiple of 64 (masked columns), D = 768."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for B, D, hidden, n_out, off in ((64, 8448, 1024, 4, 2), (7, 768, 384, 2, 0), (130, 1024, 512, 2, -1), (1, 64, 48, 1, -1),
+                                     (256, 1024, 512, 8, -1)):
+        x = torch.randn(B, D, generator=g)
+        W1, b1 = _linear_init(hidden, D, g)
+        W2, b2 = _linear_init(n_out, hidden, g)
+        ref = oheads.mlp_head(x, W1, b1, W2, b2, off)
+        cases.append(([t.to(dev) for t in (x, W1, b1, W2, b2)], off, ref))
+    tune("VPR_POSE_VARIANT", 1)                                     # the arrival-counter form
+    first = {}
+    for rep in range(6):
+        for i, (args, off, ref) in enumerate(cases):
+            out = ops.pose_head(*args, off, fused=True)
+            if rep == 0:
+                first[i] = out.clone()
+                assert (out.cpu().double() - ref).abs().max().item() < TOL, i
+            else:
+                assert torch.equal(out, first[i]), (rep, i)
+    torch.cuda.synchronize()
+    ws = ops.workspace("pose_fused", 256, dev)                      # the shared workspace: its 4 KB of counter words are all zero again
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+    # a batch so large that its counters would not fit the fixed 4 KB goes through the two-launch form by itself
+    B, D, hidden = 64 * 70, 64, 1024
+    x, (W1, b1), (W2, b2) = torch.randn(B, D, generator=g), _linear_init(hidden, D, g), _linear_init(2, hidden, g)
+    out = ops.pose_head(x.to(dev), W1.to(dev), b1.to(dev), W2.to(dev), b2.to(dev), fused=True)
+    assert (out.cpu().double() - oheads.mlp_head(x, W1, b1, W2, b2)).abs().max().item() < TOL
 
 
 def test_zero_pair_normalise_eps(dev):

@@ -107,6 +107,11 @@ PROTOTYPES = {
                                              c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vpr_pose_head_pack_w1": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "vpr_pose_head_split_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vpr_pose_head_fused_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vpr_pose_head_fused_counter_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vpr_pose_head_pack_w1_frag": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vpr_pose_head_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_pose_head_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

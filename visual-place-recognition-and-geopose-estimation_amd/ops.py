@@ -53,18 +53,21 @@ def capturing() -> bool:
 _GRAPH_PINNED: list = []       # buffers a captured graph addresses, kept alive when their cache entry is replaced
 
 
-def workspace(name: str, nbytes: int, device: torch.device, stream_key: Optional[int] = None) -> torch.Tensor:
+def workspace(name: str, nbytes: int, device: torch.device, stream_key: Optional[int] = None, zero: bool = False) -> torch.Tensor:
     """Cached byte buffer per (device, stream, name); grows, never shrinks.  Keyed by the current stream so that
     two streams driving the library concurrently (e.g. two batches in flight) never share scratch memory.  A buffer
     handed out during graph capture is never freed (a later, larger request gets a new one; the old stays pinned).
-    stream_key: raw handle of the stream that OWNS the buffer when the caller is working for it from a helper stream."""
+    stream_key: raw handle of the stream that OWNS the buffer when the caller is working for it from a helper stream.
+    zero: a new buffer is zero-filled (kernels with arrival counters at the head of their workspace need zeros on first use
+    and leave zeros behind: vpr_pose_head_fused)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, _raw_stream(idx) if stream_key is None else stream_key, name)
     ent = _WORKSPACES.get(key)
     if ent is None or ent[0].numel() < nbytes:
         if ent is not None and ent[1]:
             _GRAPH_PINNED.append(ent[0])
-        ent = _WORKSPACES[key] = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device), False]
+        alloc = torch.zeros if zero else torch.empty
+        ent = _WORKSPACES[key] = [alloc(max(int(nbytes), 256), dtype=torch.uint8, device=device), False]
     if not ent[1] and capturing():
         ent[1] = True
     return ent[0]
@@ -557,21 +560,26 @@ def topk_merge(vals: torch.Tensor, idxs: torch.Tensor) -> Tuple[torch.Tensor, to
 _POSE_PLANES: dict = {}
 
 
-def _pose_w1_planes(W1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(hi, lo) bf16 planes of a first-layer weight, packed once per (storage, version) by vpr_pose_head_pack_w1.
+def _pose_w1_planes(W1: torch.Tensor, frag: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(hi, lo) bf16 planes of a first-layer weight, packed once per (storage, version) by vpr_pose_head_pack_w1 (row-major)
+    or vpr_pose_head_pack_w1_frag (MFMA fragment order, for the single-launch kernel).
     The entry keeps a reference to W1: while it is cached its storage cannot be freed and handed to another weight
     of the same shape (a recycled address with version 0 would otherwise hit the stale planes)."""
-    key = (W1.data_ptr(), W1._version, tuple(W1.shape), str(W1.device))
+    key = (W1.data_ptr(), W1._version, tuple(W1.shape), str(W1.device), bool(frag))
     hit = _POSE_PLANES.get(key)
     if hit is None:
-        while len(_POSE_PLANES) >= 8:
+        while len(_POSE_PLANES) >= 12:
             old = _POSE_PLANES.pop(next(iter(_POSE_PLANES)))  # oldest first (dicts keep insertion order)
             if old[3]:
                 _GRAPH_PINNED.append(old)                     # a captured graph reads these planes: never freed
         hi = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
         lo = torch.empty(W1.shape, dtype=torch.bfloat16, device=W1.device)
-        st = _lib.lib().vpr_pose_head_pack_w1(_ptr(W1), W1.numel(), _ptr(hi), _ptr(lo), _stream())
-        _lib.check(st, "vpr_pose_head_pack_w1")
+        if frag:
+            st = _lib.lib().vpr_pose_head_pack_w1_frag(_ptr(W1), W1.shape[0], W1.shape[1], _ptr(hi), _ptr(lo), _stream())
+            _lib.check(st, "vpr_pose_head_pack_w1_frag")
+        else:
+            st = _lib.lib().vpr_pose_head_pack_w1(_ptr(W1), W1.numel(), _ptr(hi), _ptr(lo), _stream())
+            _lib.check(st, "vpr_pose_head_pack_w1")
         hit = _POSE_PLANES[key] = [hi, lo, W1, False]
     if not hit[3] and capturing():
         hit[3] = True
@@ -579,10 +587,14 @@ def _pose_w1_planes(W1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Tensor], W2: torch.Tensor,
-              b2: torch.Tensor, sincos_offset: int = -1, split: bool = True) -> torch.Tensor:
+              b2: torch.Tensor, sincos_offset: int = -1, split: bool = True, fused: bool = False) -> torch.Tensor:
     """W2 relu(W1 x + b1) + b2 in f32 (W1 None -> single Linear); optional unit-normalised pair.
     split: first layer as four bf16 MFMAs on (hi, lo) planes of x and W1 (f32 accuracy, ~3x faster than the
-    exact-f32 MFMA path, which split=False keeps)."""
+    exact-f32 MFMA path, which split=False keeps).  fused=True (with split): vpr_pose_head_fused — fragment-order weight
+    planes and, with VPR_POSE_VARIANT=1, ONE launch whose split-K slabs are finished by arrival counters.  Measured
+    (scripts/pose_ab.py, B = 64, D = 8448, hidden 1024): one launch 31.8 us, fragment planes + epilogue launch 22.6 us,
+    row-major planes + epilogue launch (vpr_pose_head_split, the default) 21.8 us — the serial finisher tail of the
+    counter form costs more than the second launch it removes.  All forms are bitwise reproducible."""
     _need(x, torch.float32, "x", 2)
     _need(W2, torch.float32, "W2", 2)
     _need(b2, torch.float32, "b2", 1)
@@ -601,6 +613,14 @@ def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Te
         raise RuntimeError("pose_head: b2 size")
     L = _lib.lib()
     out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    fused_bytes = L.vpr_pose_head_fused_workspace_bytes(B, D, hidden) if (hidden > 0 and split and fused) else 0
+    if fused_bytes > 0:
+        hi, lo = _pose_w1_planes(W1, frag=True)
+        ws = workspace("pose_fused", fused_bytes, x.device, zero=True)
+        st = L.vpr_pose_head_fused(_ptr(x), _ptr(hi), _ptr(lo), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), B, D, hidden,
+                                   n_out, int(sincos_offset), _ptr(ws), ws.numel(), _stream())
+        _lib.check(st, "vpr_pose_head_fused")
+        return out
     if hidden > 0 and split and D % 32 == 0 and hidden % 16 == 0:
         hi, lo = _pose_w1_planes(W1)
         ws = workspace("pose", L.vpr_pose_head_split_workspace_bytes(B, D, hidden), x.device)
