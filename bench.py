@@ -236,7 +236,7 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a, salad_step_ms=None) -> di
                                     uncertified_queries=int(unc), score_kernel=_lib.lib().vpr_knn_scores_kernel_name(1, B, N8).decode(),
                                     score_kernel_ms=ms_k, score_kernel_frac=by / ms_k / 1e6 / HBM_PEAK_GBPS, **hbm(by, ms))
         if B == 64 and N8 == 1_000_000:
-            t8, src8 = pmc_traffic("r02_knn8_pmc.json", rows["knn_topk_fp8"]["score_kernel"])
+            t8, src8 = pmc_traffic("r03_knn8_pmc.json", rows["knn_topk_fp8"]["score_kernel"])
             rows["knn_topk_fp8"].update(score_kernel_traffic=t8, traffic_source=src8)
         gr = GraphedRetrieval(ShardedGallery(g8, N8, scales=gs), B, a.k)
         qb = torch.nn.functional.normalize(torch.randn(B, D_DESC, device=dev, generator=g), dim=1).to(torch.bfloat16)
@@ -485,9 +485,9 @@ def main():
     score_kernel = _lib.lib().vpr_knn_scores_kernel_name(int(a.knn_dtype == "fp8"), bq, n_shard).decode()
     if world == 1 and a.batch == 64 and not a.graph_retrieval:
         if a.gallery == 100_000 and a.knn_dtype == "bf16":
-            traffic, traffic_source = pmc_traffic("r02_knn_pmc.json", score_kernel)
+            traffic, traffic_source = pmc_traffic("r03_knn_pmc.json", score_kernel)
         elif a.gallery == 1_000_000 and a.knn_dtype == "fp8":
-            traffic, traffic_source = pmc_traffic("r02_knn8_pmc.json", score_kernel)
+            traffic, traffic_source = pmc_traffic("r03_knn8_pmc.json", score_kernel)
 
     # knn_avg_s = the score stage alone (HIP events between the two stages of vpr_knn_topk*, same kernels as the one-call form)
     if a.graph_retrieval:

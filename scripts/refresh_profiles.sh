@@ -2,7 +2,7 @@
 # Copy the summaries of one scripts/profile_round.sh run (gpurun_out/<tag>_*) to the tracked names under profiles/.
 #   usage: bash scripts/refresh_profiles.sh r02i [r02]
 set -e
-TAG=$1; OUT=${2:-r02}
+TAG=$1; OUT=${2:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 cp $O/${TAG}_knn_pmc.json $R/profiles/${OUT}_knn_pmc.json

@@ -201,7 +201,7 @@ def test_knn_fp8_gemm_path_scores_match_stream_path(dev, tune, B):
     from vpr_amd import ops, _lib
     import ctypes
     N, D, k = 3001, 8448, 10
-    assert _lib.lib().vpr_knn_scores_kernel_name(1, B, N).decode() == ("vpr::gemm256_kernel<true>" if B in (256, 512) else "vpr::gemm_nt_fp8_kernel")
+    assert _lib.lib().vpr_knn_scores_kernel_name(1, B, N).decode() == ("vpr::gemm256_kernel<true, 10>" if B in (256, 512) else "vpr::gemm_nt_fp8_kernel")
     q, qs = _fp8_rows(B, D, 41)
     g, gs = _fp8_rows(N, D, 42)
     q, qs, g, gs = q.to(dev), qs.to(dev), g.to(dev), gs.to(dev)
@@ -379,7 +379,7 @@ def test_knn_gemm_split_k_equals_unsplit(dev, tune, fp8):
     with the unsplit one to f32 summation-order noise."""
     from vpr_amd import ops, _lib
     B, N, D, k = 512, 6378, 8448, 10
-    assert _lib.lib().vpr_knn_scores_kernel_name(int(fp8), B, N).decode() == f"vpr::gemm256_kernel<{'true' if fp8 else 'false'}>"
+    assert _lib.lib().vpr_knn_scores_kernel_name(int(fp8), B, N).decode() == f"vpr::gemm256_kernel<{'true' if fp8 else 'false'}, 10>"
     g = torch.Generator(device=dev).manual_seed(77)
     gal = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
     pos = torch.randint(0, N, (B,), device=dev, generator=g)

@@ -62,7 +62,21 @@ typedef f32x4 G2Acc[2][2][4][2];   // [qi][qj][rb][cb]: rows n = wc*64 + qj*32 +
 
 // Tile mapping, staging set-up and the K loop of one 256 x 256 output tile; returns with every wave past the last MFMA
 // (the two wave groups re-aligned), the accumulators in `acc`, the LDS-DMA tail possibly still in flight.
-template <bool FP8>
+// VM = the counted wait of the pipeline: 10 LDS-DMA instructions (five 16 KB half-tiles) stay in flight behind every wait.
+// 6 / 2 (timing-only build, VPR_GEMM256_DEPTH): the same requests, waited for two / four half-tiles earlier than needed —
+// an ablation of the prefetch distance (gathered-batch score GEMM).
+template <int VM> __device__ __forceinline__ void g2_wait_vm() {
+  if constexpr (VM == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+}
+template <int VM> __device__ __forceinline__ void g2_wait_vm_lgkm() {
+  if constexpr (VM == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+}
+
+template <bool FP8, int VM = 10>
 __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G2Acc& acc, int& m0_out, int& n0_out, int& tn_out) {
   constexpr int ES = FP8 ? 1 : 2;                       // operand element size in bytes
   const char* __restrict__ A = reinterpret_cast<const char*>(pr.A);
@@ -159,7 +173,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
   //        previous L segment, which precedes a barrier both groups pass before either reads it;
   //   WAR  a slot is refilled in the L segment after the one that read it, and every L segment
   //        ends with lgkmcnt(0), so both groups' reads are complete two barriers earlier.
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A-early / W-early of K-tile 0 (before ANY barrier)
+  g2_wait_vm<VM>();                                    // A-early / W-early of K-tile 0 (before ANY barrier)
   if (wr == 1) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
@@ -173,7 +187,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) a[rb] = g2_frag(ta, wr * 128 + rb * 16 + frow, fch);
     issue(3, kt + 1);
-    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires W-late(kt) for phase 2
+    g2_wait_vm_lgkm<VM>();                                          // retires W-late(kt) for phase 2
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -187,7 +201,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) b1[cb] = g2_frag(tw, wc * 64 + 32 + cb * 16 + frow, fch);
     issue(0, kt + 2);          // A-early slot: both groups' phase-1 reads completed two barriers ago
-    asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");   // retires A-late(kt) for phase 3
+    g2_wait_vm_lgkm<VM>();                                          // retires A-late(kt) for phase 3
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -213,7 +227,7 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
 
     // ---- phase 4: no new operands (W quadrant-col 0 is still in registers) ----
     issue(2, kt + 2);          // W-late slot (read in phase 2)
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");              // retires A-early / W-early of K-tile kt+1
+    g2_wait_vm<VM>();                                               // retires A-early / W-early of K-tile kt+1
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -227,12 +241,12 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
   m0_out = m0; n0_out = n0; tn_out = tn;
 }
 
-template <bool FP8>
+template <bool FP8, int VM = 10>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmProblem pr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   G2Acc acc;
   int m0, n0, tn_unused;
-  g2_mainloop<FP8>(pr, smem, acc, m0, n0, tn_unused);
+  g2_mainloop<FP8, VM>(pr, smem, acc, m0, n0, tn_unused);
   const int M = pr.M, N = pr.N;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -485,6 +499,22 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   g.a_scale = g.w_scale = nullptr;
   const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   if (ksplit > 1 && (g.bias != nullptr || g.relu || g.K / 64 < 2 * ksplit)) return VPR_ERR_UNSUPPORTED;   // slabs are linear partial sums
+#ifdef VPR_ABLATION
+  {   // timing-only build: shallower prefetch distance (same results)
+    const int depth = tune_or(TUNE_GEMM256_DEPTH, 10);
+    if (depth == 6 || depth == 2) {
+      static PerDeviceFlag a6 = {}, a2 = {};
+      if (depth == 6) {
+        VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<false, 6>), G2_LDS, a6));
+        VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false, 6>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
+      } else {
+        VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<false, 2>), G2_LDS, a2));
+        VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false, 2>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));
+      }
+      return VPR_OK;
+    }
+  }
+#endif
   static PerDeviceFlag attr = {};
   VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<false>), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<false>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));

@@ -1280,7 +1280,7 @@ extern "C" const char* vpr_knn_scores_kernel_name(int is_fp8, int B, int N) {
   if (!knn_plan(B, N, 8448, 10, &p)) return "";
   int nslab = 1;
   const KnnRoute route = knn_route(p, is_fp8 != 0, B, N, 8448, true, &nslab);
-  if (route == ROUTE_GEMM256) return is_fp8 ? "vpr::gemm256_kernel<true>" : "vpr::gemm256_kernel<false>";
+  if (route == ROUTE_GEMM256) return is_fp8 ? "vpr::gemm256_kernel<true, 10>" : "vpr::gemm256_kernel<false, 10>";     // (names as rocprofv3 prints them)
   if (route == ROUTE_GEMM128) return is_fp8 ? "vpr::gemm_nt_fp8_kernel" : "vpr::gemm_nt_kernel<128, 2, 2, 2>";
   const int variant = tune_or(TUNE_KNN_VARIANT, 0);
   const bool tall = variant == 3 || (variant == 0 && knn_tall_tiles(N));
