@@ -537,3 +537,47 @@ def test_knn_staged_score_stores_equal_direct(dev, tune, B, N, D, fp8, variant):
         v, i = fn(*args, ws)
         outs.append((ops.knn_scores_view(ws, B, N, D, k).clone(), v, i))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+# ----------------------------------------------------------------- the error model behind the certificate
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("route,B,N", [("stream", 64, 120_000), ("stream K-split", 64, 3000), ("gemm128", 150, 3000),
+                                       ("gemm256 K-split", 512, 6378), ("gemm256", 512, 66_000)])
+@pytest.mark.parametrize("signs", ["random", "same"])
+def test_mfma_scores_stay_inside_the_certificate_error_model(dev, fp8, route, B, N, signs):
+    """every status-0 / 1 claim rests on |S_mfma - exact| <= eps = 1.1 * D * 2^-24 * |q| * G (f32 accumulation
+    of exact products in any order).  Measured here per score route (streaming kernel, its K-split, the 128- and 256-tile
+    GEMMs incl. split-K slabs summed by the level-0 select, the block-scaled 128-deep fp8 MFMAs) at D = 8448 against exact
+    f64 dot products of the quantised operands, on unit rows with random signs and on all-positive rows (the worst case of
+    the model: sum |q_i g_i| = |q . g|): the observed error must stay below HALF of eps.  The ratio is printed."""
+    from vpr_amd import ops
+    D, k = 8448, 10
+    gen = torch.Generator(device=dev).manual_seed(B + N + int(fp8))
+    mk = lambda n: torch.randn(n, D, device=dev, generator=gen)
+    q32, g32 = mk(B), mk(N)
+    if signs == "same":
+        q32, g32 = q32.abs(), g32.abs()
+    q32, g32 = torch.nn.functional.normalize(q32, dim=1), torch.nn.functional.normalize(g32, dim=1)
+    ws = ops.knn_workspace(B, N, D, k, dev)
+    if fp8:
+        Q, qs = ops.quantize_fp8_rows(q32)
+        G, gs = ops.quantize_fp8_rows(g32)
+        ops.knn_topk_fp8(Q, qs, G, gs, k, 0, ws)
+        qd = Q.view(torch.float8_e4m3fn).double() * qs.double()[:, None]
+        bound = ops.NORM_BOUND_FP8
+        deq = lambda lo, hi: G[lo:hi].view(torch.float8_e4m3fn).double() * gs[lo:hi].double()[:, None]
+    else:
+        Q, G = q32.to(torch.bfloat16), g32.to(torch.bfloat16)
+        ops.knn_topk(Q, G, k, 0, ws)
+        qd = Q.double()
+        bound = ops.NORM_BOUND_BF16
+        deq = lambda lo, hi: G[lo:hi].double()
+    S = ops.knn_scores_view(ws, B, N, D, k)                   # MFMA scores (split-K slabs summed and written back by the select)
+    eps = 1.1 * D * 2.0 ** -24 * qd.norm(dim=1) * bound       # per query, as knn_err_rel() * |q| in knn.hip
+    worst = 0.0
+    for lo in range(0, N, 8192):                              # exact f64 scores, a slab of gallery rows at a time
+        hi = min(N, lo + 8192)
+        exact = qd @ deq(lo, hi).T
+        worst = max(worst, float(((S[:, lo:hi].double() - exact).abs() / eps[:, None]).max()))
+    print(f"\n[certificate model] {route:16s} {'e4m3' if fp8 else 'bf16'} {signs:6s}: max |S_mfma - exact| / eps = {worst:.4f}")
+    assert worst <= 0.5

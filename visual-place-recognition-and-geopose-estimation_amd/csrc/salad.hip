@@ -5,19 +5,16 @@
 // pinned at :44).  The arithmetic is not in the reference tree; oracle/salad.py restates the
 // published algorithm and tests/test_salad*.py pin both against closed-form known answers.
 //
-// Stages (one stream):
-//   skinny_linear_kernel     Ht = relu(cls W1_t^T + b1_t)  [B, hidden] bf16           token-MLP layer 1
-//   gemm256_kernel           H  = relu(X W1_sc^T + b1)  [B*n, 2*hidden] bf16           score+cluster layer 1 fused
-//   gemm_nt_group_kernel     S  = H[:, :hidden] W2_s^T + b2_s   [B*n, m] f32
-//                            F  = H[:, hidden:] W2_c^T + b2_c   [B*n, l] f32
-//                            g  = Ht W2_t^T + b2_t              [B, t] f32
-//   sinkhorn_aggregate_kernel (one workgroup per image): dustbin row, log-domain Sinkhorn in LDS
-//   (v_exp_f32 / v_log_f32 forms: ~1e-6 relative, far inside the 1e-4 descriptor tolerance; row LSE: one
-//   16-lane DPP group per row; column LSE: one thread per column), P = exp(.) as two bf16 planes,
-//   V = F^T P^T as four exact-product bf16 MFMAs on the (hi, lo) terms (f32 accuracy), the three L2
-//   normalisations, 8448 outputs (f32 + bf16 copy for the kNN stage).
-//   (Tried: 8 waves per image — the Sinkhorn iterations are exp/LDS-issue-bound per SIMD, not latency-bound:
-//   4.7 us per iteration instead of 3.4.)
+// Stages (round 3; each has its own C entry point, the one-call forms run them in one stream):
+//   T  vpr_salad_stage_token      skinny_linear_kernel x2: g = W2_t relu(W1_t cls + b1_t) + b2_t   [B, t] f32   (token MLP; in
+//                                 the pipeline it runs on the backbone's cls-row stream)
+//   M  vpr_salad_stage_mlps       gemm256_fuse2_kernel: H = relu(X W1_sc^T + b1) tile by tile, each tile multiplied from LDS
+//                                 with its W2 slice -> S [2][B*n, m], F [2][B*n, l] f32 partial-sum slabs (no H in HBM)
+//   A  vpr_salad_stage_aggregate  sinkhorn_aggregate_kernel (one workgroup per image): slab sum, dustbin row, Sinkhorn in the
+//                                 exp domain (K = exp(M - rowmax) once, then alpha / beta updates: matrix-vector products),
+//                                 P as two bf16 planes, V = F^T P^T as three exact-product bf16 MFMAs on the (hi, lo) terms
+//                                 (f32 accuracy), the three L2 normalisations, 8448 outputs (f32 + bf16 copy for the kNN stage)
+//   vpr_salad_aggregate_f32: the same at the reference's fp32 precision (three bf16 planes per operand, f32 hidden).
 #include <math.h>
 #include "vpr_common.h"
 #include "vpr_internal.h"
