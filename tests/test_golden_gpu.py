@@ -442,3 +442,60 @@ def test_cache_descriptors_from_images_equals_batchwise_extractor(dev, tmp_path)
     assert got.shape == (11, 8448)
     # batch composition differs (4 per size group vs 1): the GEMMs see other M -> compare to bf16 noise, row by row
     assert torch.nn.functional.cosine_similarity(got, ref, dim=1).min().item() > 0.9999
+
+
+def test_finetune_head_on_gpu_matches_a_reference_style_cpu_loop(dev, tmp_path):
+    """§8 f-4 on the GPU: descriptors cached by the HIP extractor (backbone + SALAD kernels), head trained on them on the
+    device by finetune.finetune_head, per-epoch validation through the HIP pose-head kernel — against a loop written the
+    reference's way (dinov2salad_finetuning.py:79-135: StandardScaler on the labels, AdamW, MSELoss, shuffled batches of 16)
+    run on the CPU in f32 on a copy of the same descriptors: same per-epoch losses (f32 GPU-vs-CPU summation noise), same
+    final weights to 1e-5, and the checkpoint it writes, loaded into DINOv2RegressionModel, predicts through the HIP path
+    what the CPU-trained torch head predicts."""
+    from vpr_amd import finetune, modules
+    torch.manual_seed(21)
+    ext = modules.DinoV2Salad("vit_small")
+    for p in ext.aggregator.parameters():
+        if p.dim() > 0:
+            torch.nn.init.normal_(p, std=0.05)
+    ext = ext.to(dev).to(torch.bfloat16).eval()
+    ext.backbone.fold_layerscale()
+    g = torch.Generator(device=dev).manual_seed(3)
+    batches = [torch.randn(8, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16) for _ in range(6)]
+    desc = finetune.cache_descriptors(ext, batches)                                   # [48, 8448] f32 from the HIP path
+    n = desc.shape[0]
+    w_true = torch.randn(8448, 2, generator=torch.Generator().manual_seed(4)) * 3
+    labels = (desc.cpu() @ w_true).numpy() * np.array([900.0, 1200.0]) + np.array([219658.0, 143506.0])
+    model = modules.DINOv2RegressionModel(ext).to(dev)
+    ref_head = torch.nn.Sequential(torch.nn.Linear(8448, 512), torch.nn.ReLU(), torch.nn.Linear(512, 2))
+    ref_head.load_state_dict({k: v.cpu() for k, v in model.regressor.state_dict().items()})
+    out = finetune.finetune_head(model, desc, labels, epochs=3, batch_size=16, lr=1e-3, save_dir=str(tmp_path),
+                                 val=(desc[:8], labels[:8]), seed=5, log=lambda s: None)
+    dcpu = desc.cpu()
+    mean, std = labels.mean(0), labels.std(0)
+    y = torch.from_numpy(((labels - mean) / std).astype(np.float32))
+    opt = torch.optim.AdamW(ref_head.parameters(), lr=1e-3)
+    gg = torch.Generator().manual_seed(5)
+    losses = []
+    for epoch in range(3):
+        perm = torch.randperm(n, generator=gg)
+        tot = 0.0
+        for lo in range(0, n, 16):
+            idx = perm[lo:lo + 16]
+            loss = torch.nn.functional.mse_loss(ref_head(dcpu[idx]), y[idx])
+            opt.zero_grad(); loss.backward(); opt.step()
+            tot += float(loss.detach())
+        losses.append(tot / 3)
+    got = [h["train_loss"] for h in out["history"]]
+    assert np.allclose(got, losses, rtol=2e-4), (got, losses)
+    assert got[-1] < got[0]
+    for a, b in zip(model.regressor.parameters(), ref_head.parameters()):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < 1e-5
+    # the written checkpoint through the HIP inference path == the CPU-trained torch head on the same descriptors
+    ck = torch.load(tmp_path / "checkpoint_2_.pth", weights_only=True)
+    fresh = modules.DINOv2RegressionModel(torch.nn.Identity()).to(dev)
+    fresh.load_state_dict({k: v for k, v in ck["model_state_dict"].items() if k.startswith("regressor.")})
+    with torch.no_grad():
+        want = ref_head(dcpu).numpy()
+    got_pred = fresh(desc).cpu().numpy()
+    assert np.abs(got_pred - want).max() < 1e-4
+    assert "val_mae" in out["history"][-1] and np.isfinite(out["history"][-1]["val_mae"])

@@ -90,7 +90,14 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
         if val is not None:
             head.eval()
             with torch.no_grad():
-                pv = head(val[0]).cpu().numpy()
+                if val[0].is_cuda:           # the per-epoch report runs the head as inference runs it: the HIP pose-head kernel
+                    from . import ops
+                    lin = [m for m in head if isinstance(m, nn.Linear)]
+                    f = lambda p: p.detach().float().contiguous()
+                    pv = ops.pose_head(val[0].float().contiguous(), f(lin[0].weight), f(lin[0].bias), f(lin[1].weight),
+                                       f(lin[1].bias)).cpu().numpy()
+                else:
+                    pv = head(val[0]).cpu().numpy()
             pv = scaler.inverse_transform(pv)
             rec["val_mae"] = float(np.mean(np.abs(pv - np.asarray(val[1]))))
         history.append(rec)
