@@ -118,6 +118,20 @@ def test_bench_two_batches_in_flight(dev):
     assert d["config"]["batches_in_flight"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["recall_at_1"] == 1.0
 
 
+def test_bench_four_ranks_gloo_rehearsal(dev):
+    """Four ranks on the one GPU (gloo), bare launch: four gallery shards (uneven: 3001 rows), 32 gathered queries per
+    shard scan, Recall@1 through the 4-way merge with positives in every shard, counters summed over the group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--no-cpu-baseline", "--no-kernel-rows",
+           "--steps", "2", "--warmup", "1", "--arch", "vit_small", "--gallery", "3001", "--batch", "8", "--no-tune"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp4+gallery-shard4"
+    assert d["recall_at_1"] == 1.0 and d["dist"]["ranks_seen"] == 4 and d["uncertified_queries"] == 0
+    assert d["roofline"]["kernel_ms"] > 0
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "self-spawn"])
 def test_bench_two_ranks_gloo_rehearsal(dev, launcher):
     """Two ranks sharing the one GPU over gloo, launched the way the driver does (torch.distributed.run) and bare
