@@ -91,6 +91,10 @@ typedef struct vpr_salad_weights {
  * n_out % 16 == 0, hidden % 256 == 0.  Done once per weight set (a 200 KB copy). */
 int vpr_salad_pack_w2_fragments(const uint16_t* w2, int n_out, int hidden, uint16_t* out, void* stream);
 
+/* WORKSPACE CONTRACT (round 3): the first 4096 bytes of the SALAD workspace are reserved for the arrival counters of the
+ * four-workgroups-per-image form of the aggregation kernel (an A/B option, VPR_SALAD_VARIANT=3; the default form does not
+ * touch them): zero before the first call on a buffer, left zero by every call — memset once after allocation; calls of
+ * different shapes may share a workspace. */
 size_t vpr_salad_workspace_bytes(int B, int n, int C, int m, int l, int t, int hidden);
 
 int vpr_salad_aggregate(const uint16_t* tokens, int B, int tokens_per_image, int C,

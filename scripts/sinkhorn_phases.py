@@ -48,7 +48,7 @@ def fuse2_phases():
     g = torch.Generator(device=dev).manual_seed(0)
     clocks = torch.zeros((4 * B, 8), dtype=torch.int64, device=dev)
     assert L.vpr_gemm256_fuse2_set_clocks(ctypes.c_void_p(clocks.data_ptr())) == 0
-    sk = torch.zeros((B, 16), dtype=torch.int64, device=dev)      # the two-slab Sinkhorn kernel of the same call
+    sk = torch.zeros((4 * B, 16), dtype=torch.int64, device=dev)  # the two-slab Sinkhorn kernel of the same call (4 workgroups per image)
     assert L.vpr_salad_sinkhorn_set_clocks(ctypes.c_void_p(sk.data_ptr())) == 0
     patch = torch.randn(B, 256, C, device=dev, generator=g).to(torch.bfloat16)
     cls = torch.randn(B, C, device=dev, generator=g).to(torch.bfloat16)
@@ -61,11 +61,14 @@ def fuse2_phases():
     torch.cuda.synchronize()
     assert L.vpr_salad_sinkhorn_set_clocks(None) == 0
     c2 = sk.cpu().double()
-    d2 = c2[:, 1:9] - c2[:, 0:8]
-    print("two slabs (inside vpr_salad_aggregate_split), median over 64 workgroups, us:")
-    for n, v in zip(NAMES, d2.median(0).values.tolist()):
+    fin = c2[:, 8] > 0                                            # workgroups that went all the way (NQ = 4: the finishers)
+    print(f"two slabs (inside vpr_salad_aggregate_split), {int(fin.sum())} finishing workgroups of {c2.shape[0]}, median, us:")
+    names2 = NAMES[:6] + ["cross-wave V, partial norms, arrival", "finisher: norms + output stores"]
+    d2 = (c2[:, 1:9] - c2[:, 0:8])[fin]
+    for n, v in zip(names2, d2.median(0).values.tolist()):
         print(f"  {n:42s} {v * 10.0 / 1e3:6.2f}")
-    print(f"  {'kernel body (first to last clock)':42s} {((c2[:, 8] - c2[:, 0]).median().item()) * 10.0 / 1e3:6.2f}")
+    print(f"  {'finisher body (first to last clock)':42s} {((c2[fin, 8] - c2[fin, 0]).median().item()) * 10.0 / 1e3:6.2f}")
+    print(f"  {'non-finishers: start to arrival':42s} {((c2[~fin, 6] - c2[~fin, 0]).median().item()) * 10.0 / 1e3:6.2f}   (clock 6 = MFMAs issued)")
     c = clocks.cpu().double()
     names = ["prologue + K loop", "W2 requests, DMA tail, barrier", "bias / ReLU / bf16 -> LDS, W2 arrival", "second-layer MFMAs", "partial-sum stores"]
     d = c[:, 1:6] - c[:, 0:5]

@@ -213,3 +213,25 @@ def test_token_mlp_on_the_backbone_cls_stream_is_bit_identical(dev):
         torch.cuda.synchronize()
         assert torch.equal(d0, d1) and torch.equal(d0h, d1h)
     ext.token_on_cls_stream = True
+
+
+def test_four_workgroups_per_image_form_equals_default(dev, tune):
+    """VPR_SALAD_VARIANT=3: the aggregation kernel with four workgroups per image (each runs the Sinkhorn, aggregates a quarter
+    of the cluster dims, the last to arrive normalises the row in place; arrival counters in the zeroed head of the workspace,
+    left zero).  An A/B option (slower: DESIGN 3.3); same descriptor as the default form to f32 summation order, bitwise
+    reproducible over repeated calls and batch sizes sharing one workspace."""
+    from vpr_amd import ops
+    g = torch.Generator().manual_seed(404)
+    for B in (5, 64, 1):
+        tokens = torch.randn(B, 257, 1024, generator=g).to(torch.bfloat16)
+        w = _weights(1024, seed=9)
+        td, wd = tokens.to(dev), _to_dev(w, dev, 1.0)
+        base, _ = ops.salad_aggregate(td, wd, 3)
+        tune("VPR_SALAD_VARIANT", 3)
+        q1, q1h = ops.salad_aggregate(td, wd, 3)
+        q2, _ = ops.salad_aggregate(td, wd, 3)
+        tune("VPR_SALAD_VARIANT", None)
+        assert torch.equal(q1, q2) and torch.equal(q1h.cpu(), q1.cpu().to(torch.bfloat16))
+        assert (q1 - base).abs().max().item() < 1e-6
+    ws = ops.workspace("salad", 256, dev)
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0

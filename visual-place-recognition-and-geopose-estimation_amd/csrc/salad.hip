@@ -75,13 +75,24 @@ __device__ long long* g_sinkhorn_clocks = nullptr;
 #define SA_CLOCK(k) do { } while (0)
 #endif
 
-template <int NSLAB>
+//
+// NQ = 4 (round 3 experiment, off by default — see launch_sinkhorn_aggregate): FOUR workgroups per image, so that a 64-image
+// batch covers all 256 CUs instead of 64 — the front of this kernel is what ONE CU can pull (~70 GB/s).  Every workgroup of an image runs the whole Sinkhorn
+// on the scores (redundant, cheap: 128 KB of loads, ~7 us of latency-bound arithmetic) but aggregates only its quarter of the
+// cluster dims (32 of 128: a quarter of the feature bytes, of the MFMAs and of the output); inside the workgroup the four
+// waves split the TOKENS (64 each) and their partial V meet in LDS.  The per-cluster norm runs over all 128 cluster dims:
+// each workgroup stores its un-normalised quarter of V straight into its final place in out_f32 and its partial sums of
+// squares into the image's token slots of out_f32 (written last anyway) — agent-scope write-through stores — and bumps the
+// image's arrival counter; the workgroup that arrives last (no spinning: the others exit) adds the four partials in quarter
+// order, normalises the whole row in place and writes the token part.  Same fixed summation orders whoever finishes:
+// bitwise reproducible.  `counters`: one int per image, zero before the first call, left zero (workspace contract).
+template <int NSLAB, int NQ>
 __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     const float* __restrict__ scores,   // [NSLAB][B, n, m]
     const float* __restrict__ feats,    // [NSLAB][B, n, l]
     const float* __restrict__ tokfeat,  // [B, t]
     long long slab_rows, float dustbin, int iters,
-    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Mx = reinterpret_cast<float*>(smem);        // [65][257] raw scores; later the two P planes
   uint16_t* Phi = reinterpret_cast<uint16_t*>(smem);      // [64][SA_PLD] bf16: hi plane of P (16-byte aligned rows)
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   float* be = al + 68;                               // [256] beta
   float* ssq = be + SA_N;                            // [4][64]
   float* red = ssq + 4 * SA_M;                       // [4]
-  const int b = blockIdx.x;
+  const int b = NQ == 4 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  const int qd = NQ == 4 ? (int)(blockIdx.x & 3) : 0;          // which quarter of the cluster dims this workgroup aggregates
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int D_OUT = SA_T + SA_L * SA_M;
 
@@ -115,13 +127,17 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   // on its 64-entry load queue — the phases just shift: what bounds the front of this kernel is the ~70 GB/s one CU
   // pulls, 192-384 KB of input, not the order of the requests.)
   const float* fb = feats + (long long)b * SA_N * SA_L;
-  const int l0 = 32 * wave;
+  const int l0 = NQ == 4 ? 32 * qd : 32 * wave;
   const int kh = lane >> 5, li = lane & 31;
-  float fa[SA_N / 32][16];
+  // NQ = 1: the wave's 32 cluster dims x all 256 tokens (8 chunks of 32 tokens); NQ = 4: the workgroup's 32 cluster dims x
+  // the WAVE's 64 tokens (2 chunks): token = tok0 + 32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)
+  constexpr int NCH = NQ == 4 ? 2 : SA_N / 32;
+  const int tok0 = NQ == 4 ? 64 * wave : 0;
+  float fa[NCH][16];
 #pragma unroll
-  for (int ch = 0; ch < SA_N / 32; ++ch)
+  for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) fa[ch][i] = fb[(32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+    for (int i = 0; i < 16; ++i) fa[ch][i] = fb[(tok0 + 32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
   float g = tokfeat[(long long)b * SA_T + tid];
 
   SA_CLOCK(1);      // loads issued
@@ -138,13 +154,13 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   Mx[SA_M * SA_LD + tid] = dustbin;
   be[tid] = 1.f;
   // second feature slab: requested now (the score registers are free again), added once K is computed
-  float fa2[NSLAB == 2 ? SA_N / 32 : 1][16];
+  float fa2[NSLAB == 2 ? NCH : 1][16];
   if constexpr (NSLAB == 2) {
     const float* fb2 = fb + slab_rows * SA_L;
 #pragma unroll
-    for (int ch = 0; ch < SA_N / 32; ++ch)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) fa2[ch][i] = fb2[(32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
+      for (int i = 0; i < 16; ++i) fa2[ch][i] = fb2[(tok0 + 32 * ch + 16 * (i >> 3) + 8 * kh + (i & 7)) * SA_L + l0 + li];
   }
   lds_barrier();
 
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   lds_barrier();                                       // al[] is about to be rewritten as alpha
   if constexpr (NSLAB == 2) {
 #pragma unroll
-    for (int ch = 0; ch < SA_N / 32; ++ch)
+    for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
       for (int i = 0; i < 16; ++i) fa[ch][i] += fa2[ch][i];
   }
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
 #pragma unroll
   for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 #pragma unroll
-  for (int ch = 0; ch < SA_N / 32; ++ch) {
+  for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       bf16x8 fh, fl;
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
         fh[e] = (__bf16)fa[ch][8 * st + e];
         fl[e] = (__bf16)(fa[ch][8 * st + e] - (float)fh[e]);
       }
-      const int j0 = 32 * ch + 16 * st + 8 * kh;
+      const int j0 = tok0 + 32 * ch + 16 * st + 8 * kh;
       const bf16x8 p0h = *reinterpret_cast<const bf16x8*>(Phi + li * SA_PLD + j0);
       const bf16x8 p0l = *reinterpret_cast<const bf16x8*>(Plo + li * SA_PLD + j0);
       const bf16x8 p1h = *reinterpret_cast<const bf16x8*>(Phi + (32 + li) * SA_PLD + j0);
@@ -276,6 +292,70 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   }
 
   SA_CLOCK(6);      // aggregation MFMAs issued (features arrived)
+  if constexpr (NQ == 4) {
+    // ---- the four waves' partial V [32 l][64 m] (each over its 64 tokens) meet in LDS; thread t then owns cluster m = t & 63,
+    //      cluster dims lq + 4 i (lq = t >> 6, i = 0..7) of this quarter ----
+    float* vred = red + 4;                                  // [4 waves][32][64] f32 = 32 KB behind the small arrays
+    __shared__ int s_last;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int l = (e & 3) + 8 * (e >> 2) + 4 * kh;        // C/D map of 32x32: col (cluster) = lane & 31, row (l) as here
+      vred[(wave * 32 + l) * SA_M + li] = acc0[e];
+      vred[(wave * 32 + l) * SA_M + 32 + li] = acc1[e];
+    }
+    __syncthreads();
+    const int m = tid & 63, lq = tid >> 6;
+    float v[8], s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int l = lq + 4 * i;
+      v[i] = (vred[(0 * 32 + l) * SA_M + m] + vred[(1 * 32 + l) * SA_M + m]) + (vred[(2 * 32 + l) * SA_M + m] + vred[(3 * 32 + l) * SA_M + m]);
+      s2 = fmaf(v[i], v[i], s2);
+    }
+    ssq[lq * SA_M + m] = s2;
+    float* ob = out_f32 + (long long)b * D_OUT;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)                             // un-normalised quarter, in its final place (agent-scope write-through)
+      __hip_atomic_store(ob + SA_T + (32 * qd + lq + 4 * i) * SA_M + m, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid < SA_M)                                         // this quarter's sums of squares -> the image's token slots (scratch until the end)
+      __hip_atomic_store(ob + qd * SA_M + tid, (ssq[tid] + ssq[SA_M + tid]) + (ssq[2 * SA_M + tid] + ssq[3 * SA_M + tid]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // write-through stores acknowledged = visible device-wide
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3);
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) __hip_atomic_store(counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SA_CLOCK(7);
+    // ---- finisher: per-cluster norm over all 128 cluster dims (quarter order), the whole row normalised in place ----
+    const float den = fmaxf(sqrtf((ob[m] + ob[SA_M + m]) + (ob[2 * SA_M + m] + ob[3 * SA_M + m])), 1e-12f);
+    float w[32], part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = ob[SA_T + (lq + 4 * i) * SA_M + m];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { w[i] = w[i] / den; part = fmaf(w[i], w[i], part); }
+    const float gn = fmaxf(sqrtf(block_sum_256(g * g, red)), 1e-12f);      // (its barriers also fence the reads of the scratch slots)
+    g = g / gn;
+    const float tot = block_sum_256(part + g * g, red);
+    const float gden = fmaxf(sqrtf(tot), 1e-12f);
+    uint16_t* obh = out_bf16 ? out_bf16 + (long long)b * D_OUT : nullptr;
+    {
+      const float o = g / gden;
+      ob[tid] = o;
+      if (obh) obh[tid] = f32_to_bf16_bits(o);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float o = w[i] / gden;
+      const int idx = SA_T + (lq + 4 * i) * SA_M + m;
+      ob[idx] = o;
+      if (obh) obh[idx] = f32_to_bf16_bits(o);
+    }
+    SA_CLOCK(8);
+    return;
+  }
   // ---- per-cluster L2 norm over l (F.normalize dim=1, eps 1e-12) ----
   {
     float s0 = 0.f, s1 = 0.f;
@@ -326,32 +406,45 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
 }
 
 constexpr size_t SINKHORN_LDS = SA_SMALL_OFF + (68 + SA_N + 4 * SA_M + 4) * sizeof(float);
+constexpr size_t SINKHORN_LDS_Q = SINKHORN_LDS + 4 * 32 * SA_M * sizeof(float);        // + the cross-wave V buffer of the NQ = 4 form
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
-                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab, long long slab_rows) {
+                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab, long long slab_rows,
+                              int* counters) {
   if (!scores || !feats || !tokfeat || !out_f32 || B <= 0 || iters < 1) return VPR_ERR_INVALID_ARG;
   if (n != SA_N || m != SA_M || l != SA_L || t != SA_T || nslab < 1 || nslab > 2) return VPR_ERR_UNSUPPORTED;
-  if (nslab == 2) {
-    static PerDeviceFlag attr2 = {};   // > 64 KiB of dynamic LDS needs the opt-in once per device
-    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<2>), SINKHORN_LDS, attr2));
-    VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel<2>, dim3(B), dim3(256), SINKHORN_LDS, stream,
-                       scores, feats, tokfeat, slab_rows, dustbin, iters, out_f32, out_bf16));
-    return VPR_OK;
+  // Four workgroups per image (NQ = 4) — built in round 3 to put all 256 CUs on a 64-image batch, measured, and left OFF:
+  // stage A 27.3 us against 20.8 us with one workgroup per image (scripts/salad_ab.py).  Every workgroup needs the whole
+  // score matrix, so the batch reads 4 x 8.4 MB of scores + 16.8 MB of features = 50 MB at once and the front becomes
+  // HBM-bound (5.9 us to issue the loads instead of 3.1), and the finisher's second pass over the row costs 4.2 us, which
+  // eats what the quartered aggregation saves.  VPR_SALAD_VARIANT=3 selects it (A/B); it needs the zeroed counter area.
+  const bool quarters = counters != nullptr && 4 * B <= device_cu_count() && tune_or(TUNE_SALAD_VARIANT, 0) == 3;
+#define VPR_SINKHORN_LAUNCH(NS, NQV, LDS, GRID)                                                                              \
+  do {                                                                                                                       \
+    static PerDeviceFlag attr = {};   /* > 64 KiB of dynamic LDS needs the opt-in once per device */                         \
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<NS, NQV>), LDS, attr));         \
+    VPR_TRY_LAUNCH(launch_kernel((sinkhorn_aggregate_kernel<NS, NQV>), dim3(GRID), dim3(256), LDS, stream, scores, feats, tokfeat, \
+                                 nslab == 2 ? slab_rows : 0LL, dustbin, iters, out_f32, out_bf16, counters));                 \
+  } while (0)
+  if (quarters) {
+    if (nslab == 2) VPR_SINKHORN_LAUNCH(2, 4, SINKHORN_LDS_Q, 4 * B); else VPR_SINKHORN_LAUNCH(1, 4, SINKHORN_LDS_Q, 4 * B);
+  } else {
+    if (nslab == 2) VPR_SINKHORN_LAUNCH(2, 1, SINKHORN_LDS, B); else VPR_SINKHORN_LAUNCH(1, 1, SINKHORN_LDS, B);
   }
-  static PerDeviceFlag attr = {};
-  VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<1>), SINKHORN_LDS, attr));
-  VPR_TRY_LAUNCH(launch_kernel(sinkhorn_aggregate_kernel<1>, dim3(B), dim3(256), SINKHORN_LDS, stream,
-                     scores, feats, tokfeat, 0LL, dustbin, iters, out_f32, out_bf16));
+#undef VPR_SINKHORN_LAUNCH
   return VPR_OK;
 }
 
 struct SaladPlan {
-  size_t off_H, off_S, off_F, off_Ht, off_g, total;
+  size_t off_cnt, off_H, off_S, off_F, off_Ht, off_g, total;
 };
+constexpr size_t SALAD_COUNTER_BYTES = 4096;     // arrival counters of the four-workgroups-per-image Sinkhorn kernel: a FIXED area at
+                                                 // the head of the workspace (zero before first use, left zero), whatever the shape
 static bool salad_plan(int B, int n, int C, int m, int l, int t, int hidden, SaladPlan* p) {
   if (B <= 0 || n <= 0 || C <= 0 || m <= 0 || l <= 0 || t <= 0 || hidden <= 0) return false;
-  size_t off = 0;
+  p->off_cnt = 0;
+  size_t off = SALAD_COUNTER_BYTES;
   p->off_H = off;  off += align_up((size_t)B * n * 2 * hidden * sizeof(uint16_t), 256);     // unfused route only
   p->off_S = off;  off += align_up((size_t)2 * B * n * m * sizeof(float), 256);              // up to two partial-sum slabs
   p->off_F = off;  off += align_up((size_t)2 * B * n * l * sizeof(float), 256);
@@ -446,8 +539,9 @@ static int salad_stage_aggregate(const SaladArgs& a, float dustbin, int sinkhorn
   const float* S = reinterpret_cast<const float*>(a.ws + a.p.off_S);
   const float* F = reinterpret_cast<const float*>(a.ws + a.p.off_F);
   const float* g = reinterpret_cast<const float*>(a.ws + a.p.off_g);
+  int* counters = (size_t)a.B * sizeof(int) <= SALAD_COUNTER_BYTES ? reinterpret_cast<int*>(a.ws + a.p.off_cnt) : nullptr;
   return launch_sinkhorn_aggregate(S, F, g, a.B, a.n, a.m, a.l, a.t, dustbin, sinkhorn_iters, out_f32, out_bf16, stream,
-                                   salad_slabs(a.n, a.C, a.m, a.l, a.hidden), (long long)a.B * a.n);
+                                   salad_slabs(a.n, a.C, a.m, a.l, a.hidden), (long long)a.B * a.n, counters);
 }
 
 }  // namespace vpr

@@ -43,7 +43,8 @@ int launch_skinny_linear(const uint16_t* in, int ldi, const uint16_t* W, int ldw
 
 int launch_sinkhorn_aggregate(const float* scores, const float* feats, const float* tokfeat,
                               int B, int n, int m, int l, int t, float dustbin, int iters,
-                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab = 1, long long slab_rows = 0);
+                              float* out_f32, uint16_t* out_bf16, hipStream_t stream, int nslab = 1, long long slab_rows = 0,
+                              int* counters = nullptr);
 
 // Launch through hipLaunchKernel(), whose return value is THIS launch's status.  (The
 // hipGetLastError() idiom reads a per-thread sticky value that other libraries in the process —

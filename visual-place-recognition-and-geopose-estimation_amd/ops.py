@@ -168,7 +168,7 @@ def salad_aggregate(tokens: torch.Tensor, w: SaladWeights, sinkhorn_iters: int =
     n = tpi - 1
     L = _lib.lib()
     nbytes = L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden)
-    ws = workspace("salad", nbytes, tokens.device)
+    ws = workspace("salad", nbytes, tokens.device, zero=True)
     out = torch.empty((B, t + l * m), dtype=torch.float32, device=tokens.device)
     out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=tokens.device) if want_bf16 else None
     cw = w.c_struct()
@@ -200,7 +200,7 @@ def salad_stage_token(cls: torch.Tensor, w: SaladWeights, n: int, owner_raw_stre
     if Ct != C:
         raise RuntimeError(f"cls {tuple(cls.shape)} does not match weights with C={C}")
     L = _lib.lib()
-    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), cls.device, stream_key=owner_raw_stream)
+    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), cls.device, stream_key=owner_raw_stream, zero=True)
     cw = w.c_struct()
     st = L.vpr_salad_stage_token(_ptr(cls), C, B, n, C, ctypes.byref(cw), m, l, t, hidden, _ptr(ws), ws.numel(), _stream())
     _lib.check(st, "vpr_salad_stage_token")
@@ -222,7 +222,7 @@ def salad_aggregate_split(patch: torch.Tensor, cls: torch.Tensor, w: SaladWeight
     if Ct != C or tuple(cls.shape) != (B, C):
         raise RuntimeError(f"patch {tuple(patch.shape)} / cls {tuple(cls.shape)} do not match weights with C={C}")
     L = _lib.lib()
-    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), patch.device)
+    ws = workspace("salad", L.vpr_salad_workspace_bytes(B, n, C, m, l, t, hidden), patch.device, zero=True)
     out = torch.empty((B, t + l * m), dtype=torch.float32, device=patch.device)
     out16 = torch.empty((B, t + l * m), dtype=torch.bfloat16, device=patch.device) if want_bf16 else None
     cw = w.c_struct()
