@@ -499,3 +499,39 @@ def test_finetune_head_on_gpu_matches_a_reference_style_cpu_loop(dev, tmp_path):
     got_pred = fresh(desc).cpu().numpy()
     assert np.abs(got_pred - want).max() < 1e-4
     assert "val_mae" in out["history"][-1] and np.isfinite(out["history"][-1]["val_mae"])
+
+
+def test_modules_run_under_torch_compile_aot_eager(dev):
+    """The op layer's torch.compile story: the head and the aggregator compiled with the `aot_eager` backend, fullgraph
+    (dynamo traces through the module, AOTAutograd runs the fake implementations of torch.ops.vpr.* to build the graph,
+    the real HIP implementations execute it) — bit-identical to the eager call."""
+    from vpr_amd import modules
+    torch.manual_seed(8)
+    pos = torch.nn.Sequential(torch.nn.Linear(8448, 512), torch.nn.ReLU(), torch.nn.Linear(512, 2)).to(dev)
+    ang = torch.nn.Sequential(torch.nn.Linear(8448, 64), torch.nn.ReLU(), torch.nn.Linear(64, 2)).to(dev)
+    head = modules.FusedGeoPoseHead(pos, ang).eval()
+    head.pack()
+    W1, b1, W2, b2 = head._packed
+    x = torch.nn.functional.normalize(torch.randn(16, 8448, device=dev), dim=1)
+
+    def head_fn(t):
+        return torch.ops.vpr.pose_head(t, W1, b1, W2, b2, 2)
+
+    ref = head_fn(x)
+    got = torch.compile(head_fn, backend="aot_eager", fullgraph=True)(x)
+    assert torch.equal(got, ref)
+    agg = modules.SaladAggregator(384).to(dev).eval()
+    for p in agg.parameters():
+        if p.dim() > 0:
+            torch.nn.init.normal_(p, std=0.05)
+    w = agg.pack()
+    wl = [getattr(w, n) for n in ("w1_sc", "b1_sc", "w2_s", "b2_s", "w2_c", "b2_c", "w1_t", "b1_t", "w2_t", "b2_t")]
+    tok = torch.randn(3, 257, 384, device=dev).to(torch.bfloat16)
+
+    def agg_fn(t):
+        d, d16 = torch.ops.vpr.salad_aggregate(t, wl, 1.0, 3)
+        return d * 1.0, d16
+
+    d_ref, _ = torch.ops.vpr.salad_aggregate(tok, wl, 1.0, 3)
+    d_got, d16 = torch.compile(agg_fn, backend="aot_eager", fullgraph=True)(tok)
+    assert torch.equal(d_got, d_ref) and torch.equal(d16, d_ref.to(torch.bfloat16))

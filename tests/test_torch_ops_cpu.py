@@ -100,3 +100,30 @@ def test_modules_export_through_torch_export():
     ep = torch.export.export(Head(), (torch.empty(8, 8448, device="meta"),), strict=False)
     targets = [n.target for n in ep.graph.nodes if n.op == "call_function"]
     assert torch.ops.vpr.pose_head.default in targets
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """bench.spawn_ranks: `python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run with the
+    driver's own flags (127.0.0.1 rendezvous, a free port, one process per GPU) and the same script arguments."""
+    import os
+    import sys
+    import types
+    import importlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5"])
+    assert bench.spawn_ranks(8) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    assert "OMP_NUM_THREADS" in seen["env"]
