@@ -31,7 +31,8 @@ for hidden in (1024, 512):
     for ks in (None, 4, 8, 12, 16, 24, 32):
         _lib.tuning_set("VPR_POSE_KS", ks)
         row = f"hidden={hidden} KS={ks if ks else 'auto':>4}:"
-        for name, kw, var in (("frag+counters", dict(fused=True), 1), ("frag+epilogue", dict(fused=True), 2), ("rowmajor+epilogue", dict(fused=False), 0)):
+        for name, kw, var in (("frag+counters", dict(fused=True), 1), ("frag+epilogue", dict(fused=True), 2),
+                              ("rowmajor 4 waves + epilogue (default)", dict(fused=False), 0), ("rowmajor 8 waves + epilogue", dict(fused=False), 8)):
             _lib.tuning_set("VPR_POSE_VARIANT", var)
             med, best = timeit(lambda: ops.pose_head(x, W1, b1, W2, b2, 2, **kw))
             row += f"  {name} {med:6.1f} us ({by / med / 1e6 / 8000:.3f})"

@@ -308,7 +308,12 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8&
 // wave's part is two or three memory round trips of 32 x 16-byte loads, x crosses the L2 once per 64 hidden
 // units, and one workgroup per CU keeps 128 KB in flight.  Partial accumulators meet in LDS; wave w finishes
 // hidden block w.
-__global__ __launch_bounds__(256, 1) void pose_l1_split_kernel(
+// NW = 8 (round 3 experiment, VPR_POSE_VARIANT=8): eight waves split the slice's K-steps, so a wave's part is ONE memory round
+// trip (two K-steps = 32 x 16-byte loads) instead of two or three; waves 4-7 hand their accumulators to waves 0-3 through the
+// same 64 KB of LDS before the four-way sum.  Measured slower (24.9 vs 22.4 us with the epilogue, scripts/pose_ab.py): the
+// kernel is not bound by its dependent round trips either; NW = 4 stays the default.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void pose_l1_split_kernel(
     const float* __restrict__ x, const uint16_t* __restrict__ Whi, const uint16_t* __restrict__ Wlo,
     float* __restrict__ part, int B, int D, int hidden, int steps_per_slice) {
   extern __shared__ __attribute__((aligned(16))) float red[];        // [4 waves][4 cb][4 mb][64 lanes][4] = 64 KB
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void pose_l1_split_kernel(
   const int ksteps = D >> 5;
   const int s_begin = ks * steps_per_slice, s_end = min(ksteps, s_begin + steps_per_slice);
   const int ns = max(s_end - s_begin, 0);
-  const int kbeg = s_begin + ns * wave / 4, kend = s_begin + ns * (wave + 1) / 4;
+  const int kbeg = s_begin + ns * wave / NW, kend = s_begin + ns * (wave + 1) / NW;
   long long wrow[4];
   const float* xp[4];
 #pragma unroll
@@ -375,12 +380,35 @@ __global__ __launch_bounds__(256, 1) void pose_l1_split_kernel(
     }
     compute(wh, wl, xa, xb);
   }
+  if constexpr (NW == 8) {                    // waves 4..7 -> LDS -> added by waves 0..3 (fixed order: own, then partner)
+    if (wave >= 4) {
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-      *reinterpret_cast<f32x4*>(red + ((((wave * 4 + cb) * 4 + mb) * 64 + lane) << 2)) = acc[cb][mb];
-  __syncthreads();
+        for (int mb = 0; mb < 4; ++mb)
+          *reinterpret_cast<f32x4*>(red + (((((wave - 4) * 4 + cb) * 4 + mb) * 64 + lane) << 2)) = acc[cb][mb];
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(red + ((((wave * 4 + cb) * 4 + mb) * 64 + lane) << 2));
+          acc[cb][mb][0] += q[0]; acc[cb][mb][1] += q[1]; acc[cb][mb][2] += q[2]; acc[cb][mb][3] += q[3];
+        }
+    }
+    __syncthreads();
+  }
+  if (wave < 4) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        *reinterpret_cast<f32x4*>(red + ((((wave * 4 + cb) * 4 + mb) * 64 + lane) << 2)) = acc[cb][mb];
+  }
+  __syncthreads();                            // (every wave of the workgroup takes part in every barrier: none leaves early)
+  if (wave >= 4) return;
   // wave w finishes hidden block w; C/D: col = batch row (lane & 15) of block mb, rows 4g+e = 4 consecutive hidden units
   const int n = n0 + wave * 16 + 4 * g;
 #pragma unroll
@@ -880,12 +908,17 @@ extern "C" int vpr_pose_head_split(const float* x, const uint16_t* W1_hi, const 
   const int sps = (ksteps + ks - 1) / ks;
   float* part = static_cast<float*>(workspace);
   constexpr size_t l1_lds = 4 * 4 * 4 * 64 * 4 * sizeof(float);   // 64 KB
-  {
+  if (tune_or(TUNE_POSE_VARIANT, 0) != 8) {        // default: four waves per workgroup (8 waves, one round trip each: 24.9 vs 22.4 us)
     static PerDeviceFlag attr = {};
-    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(pose_l1_split_kernel), l1_lds, attr));
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(pose_l1_split_kernel<4>), l1_lds, attr));
+    VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel<4>, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), l1_lds, stream, x,
+                                 W1_hi, W1_lo, part, B, D, hidden, sps));
+  } else {
+    static PerDeviceFlag attr = {};
+    VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(pose_l1_split_kernel<8>), l1_lds, attr));
+    VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel<8>, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(512), l1_lds, stream, x,
+                                 W1_hi, W1_lo, part, B, D, hidden, sps));
   }
-  VPR_TRY_LAUNCH(launch_kernel(pose_l1_split_kernel, dim3((hidden + 63) / 64, ks, (B + 63) / 64), dim3(256), l1_lds, stream, x,
-                               W1_hi, W1_lo, part, B, D, hidden, sps));
   VPR_TRY_LAUNCH(launch_kernel(pose_epilogue_kernel, dim3(B), dim3(256), 0, stream, part, ks, b1, W2, b2, out, B,
                                hidden, n_out, sincos_offset));
   return VPR_OK;
