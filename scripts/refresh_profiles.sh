@@ -8,7 +8,7 @@ O=$R/gpurun_out
 cp $O/${TAG}_knn_pmc.json $R/profiles/${OUT}_knn_pmc.json
 cp $O/${TAG}_mfma_pmc.json $R/profiles/${OUT}_mfma_pmc.json
 [ -f $O/${TAG}_knn8_pmc.json ] && cp $O/${TAG}_knn8_pmc.json $R/profiles/${OUT}_knn8_pmc.json
-cp $O/${TAG}_prof_bench/*/*_kernel_stats.csv $R/profiles/${OUT}_bench_kernel_stats.csv
+cp "$(ls -t $O/${TAG}_prof_bench/*/*_kernel_stats.csv | head -1)" $R/profiles/${OUT}_bench_kernel_stats.csv      # the newest run of that tag
 python3 $R/scripts/step_breakdown.py $O/${TAG}_prof_bench > $R/profiles/${OUT}_step_breakdown.txt
 grep -h '^{"metric"' $O/${TAG}_prof_bench.log | tail -1 > $R/profiles/${OUT}_bench_line.json
 python3 - <<PY
