@@ -4,7 +4,8 @@ last `steps` of the pipeline loop (the per-stage block that follows launches the
 groups of 4, so it is cut off by taking steps from the pipeline-shaped ones only).
 usage: step_breakdown.py <trace dir> [first_step last_step]"""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)     # the newest run under that directory
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "sinkhorn_aggregate_kernel" in r["Kernel_Name"]]
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3, 12)
