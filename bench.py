@@ -3,6 +3,7 @@
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher in the environment: the script starts the N ranks itself, same command as above)
 
 A step = one batch of B synthetic 3x224x224 images per GPU through DINOv2 ViT-L/14 (PyTorch-ROCm,
 random init) -> SALAD aggregation (HIP) -> bf16 cosine top-k against the 100k-row synthetic
@@ -10,7 +11,10 @@ gallery, row-sharded over the ranks (HIP; RCCL all-gather of queries and of per-
 on-device merge) -> fused (lat, lon, sin, cos) head (HIP).  Weak scaling: B per GPU is fixed.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
 hand-written kernel (the HBM-bound kNN score kernel, timed live with HIP events inside the timed
-region) and `cpu_baseline` (oracle/ + the same backbone on the host cores, bounded sample).
+region), `kernels` (one roofline row per other hand-written stage; the SALAD row is measured live
+inside the timed region too), `recall_at_1` (planted positives, through all-gather + merge when the
+gallery is sharded), `dist` (process group, ranks it really has, exchange time per step) and
+`cpu_baseline` (oracle/ + the same backbone on the host cores, bounded sample).
 """
 import argparse
 import json
