@@ -48,6 +48,43 @@ def _ln(norm: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
     return norm(x)
 
 
+class _StreamSignals:
+    """Fork / join between two HIP streams through stream memory operations (hipStreamWriteValue32 on the producer stream,
+    hipStreamWaitValue32 on the consumer stream, one 32-bit word of signal memory per direction, values from a counter that
+    only grows) instead of hipEventRecord + hipStreamWaitEvent.  Round-3 experiment, OFF by default: an event operation costs
+    the launch stream ~7 us of queue time whether or not anything has to be waited for (scripts/step_gaps.py: 14 us per block
+    of the ViT), and in a two-GEMM probe the memory operations are cheaper (scripts/stream_sync_probe.py: 21 -> 13.5 us per
+    fork + join pair) — but in the real step they are slower: 11.7-11.9 vs 11.31 ms per step (bench.py --stream-signals, two
+    runs each, one box).  A wait is only ever enqueued AFTER its write has been enqueued, so no stream can be left waiting
+    for a value that never comes."""
+
+    def __init__(self, device: torch.device):
+        import ctypes
+        import os
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))     # the runtime torch itself uses
+        hip.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        hip.hipStreamWriteValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint]
+        hip.hipStreamWaitValue32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint, ctypes.c_uint32]
+        hip.hipFree.argtypes = [ctypes.c_void_p]
+        self._hip, self._words, self.count = hip, [], 0
+        with torch.cuda.device(device):
+            for _ in range(2):
+                p = ctypes.c_void_p()
+                if hip.hipExtMallocWithFlags(ctypes.byref(p), 8, 0x2) != 0:          # hipMallocSignalMemory
+                    raise RuntimeError("hipExtMallocWithFlags(hipMallocSignalMemory) failed")
+                self._words.append(p)
+
+    def signal(self, word: int, stream: torch.cuda.Stream, value: int) -> None:
+        if self._hip.hipStreamWriteValue32(stream.cuda_stream, self._words[word], value & 0xFFFFFFFF, 0) != 0:
+            raise RuntimeError("hipStreamWriteValue32 failed")
+
+    def wait(self, word: int, stream: torch.cuda.Stream, value: int) -> None:
+        # hipStreamWaitValueEq: the words only ever hold the value of the latest signal, and a wait for value v is enqueued
+        # before the signal for v + 1 can be (program order of the loop), so equality is exact even across the 2^32 wrap
+        if self._hip.hipStreamWaitValue32(stream.cuda_stream, self._words[word], value & 0xFFFFFFFF, 0x1, 0xFFFFFFFF) != 0:
+            raise RuntimeError("hipStreamWaitValue32 failed")
+
+
 class SplitTokens(NamedTuple):
     """Final-norm tokens as the HIP backbone path holds them: patch [B, n, C] and cls [B, C], both
     contiguous (vpr_salad_aggregate_split consumes the pair without a copy).  token_ready: the backbone's cls-row
@@ -230,6 +267,8 @@ class DinoV2(nn.Module):
         return ent[0], ent[1]
 
     cls_side_chain = True
+    stream_signals = False      # fork / join of the cls side chain by stream memory operations instead of events: measured SLOWER in the
+                                # step (11.7-11.9 vs 11.31 ms, bench.py --stream-signals) although the two-GEMM probe favours it
 
     def _blocks_side_chain(self, x: torch.Tensor, h: torch.Tensor, cum: torch.Tensor, B: int, n: int, C: int) -> "SplitTokens":
         """The 24 blocks with the cls rows on their own stream.  Between two attentions the B cls rows need six
@@ -255,6 +294,12 @@ class DinoV2(nn.Module):
             import os
             prio = int(os.environ.get("VPR_SIDE_PRIORITY", "-1"))
             side = sides[skey] = torch.cuda.Stream(device=dev, priority=prio)
+        sig = None
+        if self.stream_signals and not torch.cuda.is_current_stream_capturing():
+            sigs = self.__dict__.setdefault("_signals", {})
+            sig = sigs.get(skey)
+            if sig is None:
+                sig = sigs[skey] = _StreamSignals(dev)
         C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
         xp, xc = x[:Mp], x[Mp:]
         hp = h[:Mp]
@@ -268,9 +313,15 @@ class DinoV2(nn.Module):
             nxt = nb.norm1 if not last else self.norm
             att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
             qkv_next = torch.empty((M, C3), dtype=bf, device=dev) if not last else None
-            fork = torch.cuda.Event()
-            fork.record(main)
-            side.wait_event(fork)
+            if sig is not None:
+                sig.count += 1
+                tick = sig.count
+                sig.signal(0, main, tick)
+                sig.wait(0, side, tick)
+            else:
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)
             with torch.cuda.stream(side):
                 ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, xc, 2)
                 hc = ops.bias_layernorm_bf16(xc, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
@@ -285,8 +336,11 @@ class DinoV2(nn.Module):
                     if self.cls_tail_hook is not None:     # e.g. SALAD's token MLP: needs the cls rows only, rides on this stream
                         self.cls_tail_hook(cls_out, main.cuda_stream)
                         hooked = True
-                join = torch.cuda.Event()
-                join.record(side)
+                if sig is not None:
+                    sig.signal(1, side, tick)
+                else:
+                    join = torch.cuda.Event()
+                    join.record(side)
             xp.addmm_(att[:Mp], blk.proj.weight.t())
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hh = self._fc1_gelu(blk, hp)
@@ -294,7 +348,10 @@ class DinoV2(nn.Module):
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
             if not last:
                 torch.addmm(nb.qkv.bias, hp, nb.qkv.weight.t(), out=qkv_next[:Mp])
-            main.wait_event(join)          # the side chain finished ~0.3 ms ago: satisfied on arrival
+            if sig is not None:            # the side chain finished ~0.3 ms ago: satisfied on arrival
+                sig.wait(1, main, tick)
+            else:
+                main.wait_event(join)
             qkv = qkv_next                 # (att stayed referenced up to here)
         return SplitTokens(hp.view(B, n, C), cls_out, hooked)
 
