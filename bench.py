@@ -358,7 +358,8 @@ def main():
     ap.add_argument("--knn-dtype", choices=["bf16", "fp8"], default="bf16",
                     help="gallery / query storage for the kNN stage: bf16 (headline) or e4m3 + per-row scale (BASELINE config 5 flavour)")
     ap.add_argument("--no-side-chain", action="store_true", help="cls-row kernels in the main stream instead of a side stream forked / joined once per block (A/B)")
-    ap.add_argument("--stream-signals", action="store_true", help="fork / join of the cls side chain by stream memory operations instead of HIP events (A/B: slower)")
+    ap.add_argument("--side-sync", choices=("events", "light", "signals"), default=None,
+                    help="fork / join of the cls side chain (A/B): torch events, HIP events without the system-scope fence, stream memory operations")
     ap.add_argument("--in-flight", type=int, default=1, help="independent batches in flight (one stream each); 1 = strictly sequential steps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets 2 ranks rehearse on one GPU")
     ap.add_argument("--force-dist", action="store_true",
@@ -414,7 +415,8 @@ def main():
     ext.backbone.fuse_ln_cls = a.fuse_ln_cls
     ext.backbone.cls_after_gemm = not a.cls_before_gemm
     ext.backbone.cls_side_chain = not a.no_side_chain
-    ext.backbone.stream_signals = a.stream_signals
+    if a.side_sync is not None:
+        ext.backbone.side_sync = a.side_sync
     ext.backbone.auto_fold = not a.no_fold
     if not a.no_fold:
         ext.backbone.fold_layerscale()          # inference-only: two fewer elementwise passes per block

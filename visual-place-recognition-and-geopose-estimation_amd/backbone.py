@@ -54,7 +54,7 @@ class _StreamSignals:
     only grows) instead of hipEventRecord + hipStreamWaitEvent.  Round-3 experiment, OFF by default: an event operation costs
     the launch stream ~7 us of queue time whether or not anything has to be waited for (scripts/step_gaps.py: 14 us per block
     of the ViT), and in a two-GEMM probe the memory operations are cheaper (scripts/stream_sync_probe.py: 21 -> 13.5 us per
-    fork + join pair) — but in the real step they are slower: 11.7-11.9 vs 11.31 ms per step (bench.py --stream-signals, two
+    fork + join pair) — but in the real step they are slower: 11.7-11.9 vs 11.31 ms per step (bench.py --side-sync signals, two
     runs each, one box).  A wait is only ever enqueued AFTER its write has been enqueued, so no stream can be left waiting
     for a value that never comes."""
 
@@ -83,6 +83,85 @@ class _StreamSignals:
         # before the signal for v + 1 can be (program order of the loop), so equality is exact even across the 2^32 wrap
         if self._hip.hipStreamWaitValue32(stream.cuda_stream, self._words[word], value & 0xFFFFFFFF, 0x1, 0xFFFFFFFF) != 0:
             raise RuntimeError("hipStreamWaitValue32 failed")
+
+    # the three-call protocol _blocks_side_chain uses (same as _TorchEvents / _RawEvents)
+    def fork(self, main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
+        self.count += 1
+        self.signal(0, main, self.count)
+        self.wait(0, side, self.count)
+
+    def mark(self, side: torch.cuda.Stream) -> int:
+        self.signal(1, side, self.count)
+        return self.count
+
+    def join(self, main: torch.cuda.Stream, tick: int) -> None:
+        self.wait(1, main, tick)
+
+
+class _TorchEvents:
+    """Fork / join by torch.cuda.Event (hipEventDisableTiming; the record carries a system-scope release)."""
+
+    def fork(self, main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
+        e = torch.cuda.Event()
+        e.record(main)
+        side.wait_event(e)
+
+    def mark(self, side: torch.cuda.Stream) -> "torch.cuda.Event":
+        e = torch.cuda.Event()
+        e.record(side)
+        return e
+
+    def join(self, main: torch.cuda.Stream, e: "torch.cuda.Event") -> None:
+        main.wait_event(e)
+
+
+class _RawEvents:
+    """Fork / join by HIP events created with hipEventDisableTiming | hipEventDisableSystemFence (torch.cuda.Event cannot pass
+    the second flag): the record then carries no system-scope cache writeback / invalidate — both streams are queues of
+    the same device, device scope is all the hand-over needs.  A ring of events: a wait refers to the record that was
+    latest when the wait was enqueued, so re-recording an event later never disturbs a wait already in a queue."""
+    RING = 128
+
+    def __init__(self, device: torch.device, flags: int = 0x2 | 0x20000000):
+        import ctypes
+        import os
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self._hip, self._ring, self._next = hip, [], 0
+        with torch.cuda.device(device):
+            for _ in range(self.RING):
+                e = ctypes.c_void_p()
+                st = hip.hipEventCreateWithFlags(ctypes.byref(e), flags)
+                if st != 0:
+                    raise RuntimeError(f"hipEventCreateWithFlags(0x{flags:x}) failed: hipError {st}")
+                self._ring.append(e)
+
+    def __del__(self):
+        for e in getattr(self, "_ring", []):
+            self._hip.hipEventDestroy(e)
+
+    def _record(self, stream: torch.cuda.Stream):
+        e = self._ring[self._next]
+        self._next = (self._next + 1) % self.RING
+        if self._hip.hipEventRecord(e, stream.cuda_stream) != 0:
+            raise RuntimeError("hipEventRecord failed")
+        return e
+
+    def _wait(self, stream: torch.cuda.Stream, e) -> None:
+        if self._hip.hipStreamWaitEvent(stream.cuda_stream, e, 0) != 0:
+            raise RuntimeError("hipStreamWaitEvent failed")
+
+    def fork(self, main: torch.cuda.Stream, side: torch.cuda.Stream) -> None:
+        self._wait(side, self._record(main))
+
+    def mark(self, side: torch.cuda.Stream):
+        return self._record(side)
+
+    def join(self, main: torch.cuda.Stream, e) -> None:
+        self._wait(main, e)
 
 
 class SplitTokens(NamedTuple):
@@ -267,8 +346,9 @@ class DinoV2(nn.Module):
         return ent[0], ent[1]
 
     cls_side_chain = True
-    stream_signals = False      # fork / join of the cls side chain by stream memory operations instead of events: measured SLOWER in the
-                                # step (11.7-11.9 vs 11.31 ms, bench.py --stream-signals) although the two-GEMM probe favours it
+    side_sync = "events"        # fork / join of the cls side chain: "events" (torch.cuda.Event), "light" (HIP events without the system-scope
+                                # fence, _RawEvents), "signals" (stream memory operations, _StreamSignals: measured SLOWER in the step,
+                                # 11.7-11.9 vs 11.31 ms, although the two-GEMM probe favours them).  bench.py --side-sync
 
     def _blocks_side_chain(self, x: torch.Tensor, h: torch.Tensor, cum: torch.Tensor, B: int, n: int, C: int) -> "SplitTokens":
         """The 24 blocks with the cls rows on their own stream.  Between two attentions the B cls rows need six
@@ -294,12 +374,16 @@ class DinoV2(nn.Module):
             import os
             prio = int(os.environ.get("VPR_SIDE_PRIORITY", "-1"))
             side = sides[skey] = torch.cuda.Stream(device=dev, priority=prio)
-        sig = None
-        if self.stream_signals and not torch.cuda.is_current_stream_capturing():
-            sigs = self.__dict__.setdefault("_signals", {})
-            sig = sigs.get(skey)
-            if sig is None:
-                sig = sigs[skey] = _StreamSignals(dev)
+        mode = self.side_sync if not torch.cuda.is_current_stream_capturing() else "events"     # capture: plain event nodes
+        if mode not in ("events", "light", "signals"):
+            raise RuntimeError(f"DinoV2.side_sync: unknown mode {mode!r}")
+        if mode == "events":
+            sync = _TorchEvents()
+        else:
+            syncs = self.__dict__.setdefault("_syncs", {})
+            sync = syncs.get(skey + (mode,))
+            if sync is None:
+                sync = syncs[skey + (mode,)] = _StreamSignals(dev) if mode == "signals" else _RawEvents(dev)
         C3, C4 = blocks[0].qkv.weight.shape[0], blocks[0].fc1.weight.shape[0]
         xp, xc = x[:Mp], x[Mp:]
         hp = h[:Mp]
@@ -313,15 +397,7 @@ class DinoV2(nn.Module):
             nxt = nb.norm1 if not last else self.norm
             att = ops.attention_qkv_split_bf16(qkv, B, 1 + n, n, blk.heads)
             qkv_next = torch.empty((M, C3), dtype=bf, device=dev) if not last else None
-            if sig is not None:
-                sig.count += 1
-                tick = sig.count
-                sig.signal(0, main, tick)
-                sig.wait(0, side, tick)
-            else:
-                fork = torch.cuda.Event()
-                fork.record(main)
-                side.wait_event(fork)
+            sync.fork(main, side)
             with torch.cuda.stream(side):
                 ops.skinny_linear_bf16(att[Mp:], blk.proj.weight, None, xc, 2)
                 hc = ops.bias_layernorm_bf16(xc, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
@@ -336,11 +412,7 @@ class DinoV2(nn.Module):
                     if self.cls_tail_hook is not None:     # e.g. SALAD's token MLP: needs the cls rows only, rides on this stream
                         self.cls_tail_hook(cls_out, main.cuda_stream)
                         hooked = True
-                if sig is not None:
-                    sig.signal(1, side, tick)
-                else:
-                    join = torch.cuda.Event()
-                    join.record(side)
+                joined = sync.mark(side)
             xp.addmm_(att[:Mp], blk.proj.weight.t())
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i], blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             hh = self._fc1_gelu(blk, hp)
@@ -348,10 +420,7 @@ class DinoV2(nn.Module):
             hp = ops.bias_layernorm_bf16(xp, cum[2 * i + 1], nxt.weight, nxt.bias, nxt.eps)
             if not last:
                 torch.addmm(nb.qkv.bias, hp, nb.qkv.weight.t(), out=qkv_next[:Mp])
-            if sig is not None:            # the side chain finished ~0.3 ms ago: satisfied on arrival
-                sig.wait(1, main, tick)
-            else:
-                main.wait_event(join)
+            sync.join(main, joined)        # the side chain finished ~0.3 ms ago: satisfied on arrival
             qkv = qkv_next                 # (att stayed referenced up to here)
         return SplitTokens(hp.view(B, n, C), cls_out, hooked)
 
