@@ -337,6 +337,30 @@ int vpr_pose_head_fused(const float* x, const uint16_t* W1_hi_frag, const uint16
                         int n_out, int sincos_offset, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One optimizer step of the two-layer regression head on CACHED descriptors (head-only fine-tuning):
+ *   preds = W2 relu(W1 x + b1) + b2 ; loss = mean((preds - y)^2) over the B * n_out elements ; backward ; AdamW.
+ * Replaces, per batch, dinov2salad/dinov2salad_finetuning.py:119-125 (`preds = model(inputs)`, `loss_fn(preds, targets)`,
+ * `optimizer.zero_grad()`, `loss.backward()`, `optimizer.step()`) with `optimizer = torch.optim.AdamW(lr=1e-5)` (:95) and
+ * `loss_fn = nn.MSELoss()` (:96), for a frozen extractor whose descriptors were computed once.
+ * X [rows, x_stride] f32 descriptors, Y [rows, y_stride] f32 (standardised) targets; idx [B] int32 device = the rows of this
+ * batch (NULL: rows 0..B-1; the caller guarantees 0 <= idx < rows).  W1 [hidden, D], b1 [hidden], W2 [n_out, hidden],
+ * b2 [n_out]: f32, updated IN PLACE.  m, v: AdamW moments, vpr_head_train_state_floats() floats each, laid out
+ * [W1 | b1 | W2 | b2], zero before step 1, updated in place.  step = 1, 2, ... (number of this update: bias corrections).
+ * Hyper-parameters are doubles, as Python holds them; every derived scalar (1 - lr*wd, lr / (1 - beta1^step), ...) is formed in
+ * double and rounded to f32 once, and the update follows torch.optim.AdamW's order of operations.
+ * loss_out (device, may be NULL) receives this batch's loss (before the update).  All arithmetic f32 with fixed summation
+ * orders: bitwise reproducible.  The gradient of W1 is never written to memory (formed in registers, consumed by the update).
+ * Requires 1 <= B <= 64, D % 16 == 0, hidden % 32 == 0, 1 <= n_out <= 8, x_stride % 4 == 0, 16-byte aligned X / W1 / m / v /
+ * workspace; workspace contents are scratch.  Status codes as everywhere (VPR_ERR_UNSUPPORTED for other shapes).
+ * ------------------------------------------------------------------------------------------ */
+size_t vpr_head_train_workspace_bytes(int B, int D, int hidden, int n_out);
+long long vpr_head_train_state_floats(int D, int hidden, int n_out);
+int vpr_head_train_step(const float* X, long long x_stride, const int* idx, const float* Y, long long y_stride,
+                        int B, int D, int hidden, int n_out, float* W1, float* b1, float* W2, float* b2,
+                        float* m, float* v, int step, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh
  * Replaces: `outputs.pooler_output` + `self.regressor`  swin_transformer/swin_validation.py:43-46
  *           (HF SwinModel: layernorm -> AdaptiveAvgPool1d(1) over tokens) and the normalised

@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  MUST precede loading libvpr_amd.so: the library has to bind to the HIP
               # runtime PyTorch ships (torch/lib/libamdhip64.so), not to a second copy from /opt/rocm —
               # two runtimes in one process make every launch fail with hipErrorNoDevice.
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -114,6 +114,11 @@ PROTOTYPES = {
                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "vpr_pose_head_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "vpr_head_train_workspace_bytes": (c_size_t, [c_int] * 4),
+    "vpr_head_train_state_floats": (c_longlong, [c_int] * 3),
+    "vpr_head_train_step": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),

@@ -7,8 +7,12 @@ labels (:79-81), `Linear(8448,512)-ReLU-Linear(512,2)` trained with AdamW(lr=1e-
 
 MI355X-first difference: the extractor is frozen, so its descriptors are computed ONCE by the HIP
 path (backbone -> vpr_salad_aggregate) and cached in HBM ([N,8448] f32, 215 MB for the 6378
-training images) instead of re-running the backbone every epoch as the reference does; the head
-itself (8.6 MFLOP/image) trains with PyTorch autograd on those cached descriptors.
+training images) instead of re-running the backbone every epoch as the reference does; on a GPU the
+head's training step itself (forward, MSELoss, backward, AdamW: dinov2salad_finetuning.py:119-125) is
+the HIP entry point vpr_head_train_step — three launches per batch, no host synchronisation inside an
+epoch, the 17 MB gradient of W1 never written to memory — checked against oracle/finetune.py (pinned to
+torch autograd + torch.optim.AdamW).  engine="torch" keeps the PyTorch-autograd loop (CPU tensors, or an
+explicit A/B on the GPU: scripts/head_train_bench.py).
 """
 from __future__ import annotations
 
@@ -55,11 +59,21 @@ def cache_descriptors_from_images(extractor: nn.Module, image_dir: str, filename
 
 def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, labels: np.ndarray,
                   epochs: int = 100, batch_size: int = 16, lr: float = 1e-5, save_dir: Optional[str] = None,
-                  val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print) -> dict:
+                  val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print,
+                  engine: str = "auto") -> dict:
     """Trains model.regressor on cached descriptors.  labels [N,2] raw (lat, lon); they are
     standardised with a scaler fitted here (returned and, if save_dir, dumped as JSON).
-    val = (val_descriptors, val_labels_raw) for the per-epoch de-normalised report."""
+    val = (val_descriptors, val_labels_raw) for the per-epoch de-normalised report.
+    engine: "hip" = vpr_head_train_step (GPU descriptors; raises if the head is not Linear-ReLU-Linear of a supported
+    shape), "torch" = PyTorch autograd + torch.optim.AdamW, "auto" = "hip" for GPU descriptors, "torch" for CPU ones.
+    Both engines draw the same batches (same seeded permutations) and write the same checkpoint format."""
     dev = descriptors.device
+    if engine not in ("auto", "hip", "torch"):
+        raise ValueError(f"finetune_head: unknown engine {engine!r}")
+    if engine == "auto":
+        engine = "hip" if descriptors.is_cuda else "torch"
+    if engine == "hip" and not descriptors.is_cuda:
+        raise RuntimeError("finetune_head: engine='hip' needs the descriptors on the GPU (there is no CPU fallback)")
     scaler = LatLonScaler.fit(labels)
     y = torch.from_numpy(scaler.transform(np.asarray(labels, dtype=np.float64)).astype(np.float32)).to(dev)
     head = model.regressor.to(dev).float()
@@ -67,6 +81,7 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
         p.requires_grad_(True)
     opt = torch.optim.AdamW(head.parameters(), lr=lr)
     loss_fn = nn.MSELoss()
+    hip = _HipHeadTrainer(head, descriptors.float().contiguous(), y, opt) if engine == "hip" else None
     g = torch.Generator(device="cpu").manual_seed(seed)
     n = descriptors.shape[0]
     history = []
@@ -78,14 +93,19 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
         head.train()
         perm = torch.randperm(n, generator=g).to(dev)
         total, nb = 0.0, 0
-        for lo in range(0, n, batch_size):
-            idx = perm[lo:lo + batch_size]
-            loss = loss_fn(head(descriptors[idx]), y[idx])
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            total += float(loss.detach())
-            nb += 1
+        if engine == "hip":
+            loss = hip.epoch(perm, batch_size)
+            total, nb = float(loss.sum()), loss.numel()        # the epoch's only host synchronisation
+            loss = loss[-1]
+        else:
+            for lo in range(0, n, batch_size):
+                idx = perm[lo:lo + batch_size]
+                loss = loss_fn(head(descriptors[idx]), y[idx])
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                total += float(loss.detach())
+                nb += 1
         rec = {"epoch": epoch, "train_loss": total / max(nb, 1)}
         if val is not None:
             head.eval()
@@ -103,12 +123,60 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
         history.append(rec)
         log(f"Epoch {epoch + 1} - Train Loss: {rec['train_loss']:.4f}" + (f" - Val MAE: {rec['val_mae']:.2f}" if val else ""))
         if save_dir:
+            if hip is not None:
+                hip.export_optimizer_state()
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
                         "optimizer_state_dict": opt.state_dict(), "loss": loss.detach()},
                        os.path.join(save_dir, f"checkpoint_{epoch}_.pth"))
+    if hip is not None:
+        hip.export_optimizer_state()
     for p in head.parameters():
         p.requires_grad_(False)
-    return {"scaler": scaler, "history": history}
+    return {"scaler": scaler, "history": history, "engine": engine, "optimizer": opt}
+
+
+class _HipHeadTrainer:
+    """The HIP training step driven over an epoch: parameters are the nn.Linear tensors themselves (updated in place by the
+    kernels), AdamW moments live in two flat buffers ([W1 | b1 | W2 | b2]) and are copied into a torch.optim.AdamW's state
+    only when a checkpoint wants `optimizer.state_dict()` (the reference's checkpoint dict, :130-135)."""
+
+    def __init__(self, head: nn.Module, X: torch.Tensor, Y: torch.Tensor, opt: torch.optim.Optimizer):
+        from . import ops
+        lin = [m for m in head if isinstance(m, nn.Linear)]
+        rest = [m for m in head if not isinstance(m, (nn.Linear, nn.ReLU))]
+        if len(lin) != 2 or rest or not isinstance(head[1], nn.ReLU):
+            raise RuntimeError("finetune_head(engine='hip'): the head must be Linear -> ReLU -> Linear (dinov2salad_finetuning.py:28-32)")
+        self.ops, self.opt, self.X, self.Y = ops, opt, X, Y.contiguous()
+        self.params = [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias]
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise RuntimeError("finetune_head(engine='hip'): head parameters must be contiguous f32 GPU tensors")
+        self.W1, self.b1, self.W2, self.b2 = (p.detach() for p in self.params)     # aliases that share the parameters' version counters
+        self.m, self.v = ops.head_train_state(self.W1, self.W2)
+        grp = opt.param_groups[0]
+        self.hyper = dict(lr=grp["lr"], betas=tuple(grp["betas"]), eps=grp["eps"], weight_decay=grp["weight_decay"])
+        self.step = 0
+
+    def epoch(self, perm: torch.Tensor, batch_size: int) -> torch.Tensor:
+        """One pass in the order `perm` (ragged last batch kept, as DataLoader's default does: :89).  Returns the batch losses
+        (device tensor; nothing here waits for the GPU)."""
+        perm32 = perm.to(device=self.X.device, dtype=torch.int32).contiguous()
+        n = perm32.numel()
+        nb = (n + batch_size - 1) // batch_size
+        losses = torch.empty(nb, dtype=torch.float32, device=self.X.device)
+        for i in range(nb):
+            self.step += 1
+            self.ops.head_train_step(self.X, self.Y, perm32[i * batch_size:(i + 1) * batch_size], self.W1, self.b1, self.W2,
+                                     self.b2, self.m, self.v, self.step, loss_out=losses[i:i + 1], **self.hyper)
+        return losses
+
+    def export_optimizer_state(self) -> None:
+        """Fill the torch optimizer's per-parameter state (step, exp_avg, exp_avg_sq) from the flat moment buffers."""
+        ms = self.ops.head_train_state_views(self.m, self.W1, self.W2)
+        vs = self.ops.head_train_state_views(self.v, self.W1, self.W2)
+        for p, mm, vv in zip(self.params, ms, vs):
+            self.opt.state[p] = {"step": torch.tensor(float(self.step)), "exp_avg": mm.clone().view_as(p),
+                                 "exp_avg_sq": vv.clone().view_as(p)}
 
 
 # ------------------------------------------------------------------------------------- angle heads

@@ -635,6 +635,70 @@ def pose_head(x: torch.Tensor, W1: Optional[torch.Tensor], b1: Optional[torch.Te
     return out
 
 
+def head_train_state(W1: torch.Tensor, W2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Zeroed AdamW moment buffers (m, v) for vpr_head_train_step, laid out [W1 | b1 | W2 | b2]."""
+    hidden, D = W1.shape
+    n = _lib.lib().vpr_head_train_state_floats(D, hidden, W2.shape[0])
+    return (torch.zeros(n, dtype=torch.float32, device=W1.device), torch.zeros(n, dtype=torch.float32, device=W1.device))
+
+
+def head_train_state_views(buf: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor):
+    """The four per-parameter views (W1, b1, W2, b2 shaped) of one moment buffer."""
+    hidden, D = W1.shape
+    n_out = W2.shape[0]
+    o1 = hidden * D
+    o2 = o1 + hidden
+    o3 = o2 + n_out * hidden
+    return buf[:o1].view(hidden, D), buf[o1:o2], buf[o2:o3].view(n_out, hidden), buf[o3:o3 + n_out]
+
+
+def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor], W1: torch.Tensor, b1: torch.Tensor,
+                    W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-5,
+                    betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                    loss_out: Optional[torch.Tensor] = None) -> None:
+    """One batch of head-only fine-tuning on cached descriptors (vpr_head_train_step): forward, MSELoss, backward and
+    AdamW update of Linear(D,hidden)-ReLU-Linear(hidden,n_out), in place on W1 / b1 / W2 / b2 / m / v.
+    X [rows, D] f32, Y [rows, n_out] f32, idx [B] int32 (rows of the batch; None = all rows of X in order).  loss_out: a
+    one-element f32 tensor (e.g. losses[i:i+1]) that receives the batch loss.  No host synchronisation."""
+    _need(X, torch.float32, "X", 2)
+    _need(Y, torch.float32, "Y", 2)
+    _need(W1, torch.float32, "W1", 2)
+    _need(b1, torch.float32, "b1", 1)
+    _need(W2, torch.float32, "W2", 2)
+    _need(b2, torch.float32, "b2", 1)
+    _need(m, torch.float32, "m", 1)
+    _need(v, torch.float32, "v", 1)
+    hidden, D = W1.shape
+    n_out = W2.shape[0]
+    if X.shape[1] != D or Y.shape[0] != X.shape[0] or Y.shape[1] != n_out or b1.numel() != hidden or W2.shape[1] != hidden \
+            or b2.numel() != n_out:
+        raise RuntimeError("head_train_step: inconsistent shapes")
+    if idx is not None:
+        _need(idx, torch.int32, "idx", 1)
+        B = idx.numel()
+    else:
+        B = X.shape[0]
+    L = _lib.lib()
+    if m.numel() != L.vpr_head_train_state_floats(D, hidden, n_out) or v.numel() != m.numel():
+        raise RuntimeError("head_train_step: moment buffers must hold vpr_head_train_state_floats() floats (ops.head_train_state)")
+    if loss_out is not None:
+        _need(loss_out, torch.float32, "loss_out")
+        if loss_out.numel() != 1:
+            raise RuntimeError("head_train_step: loss_out must have one element")
+    nbytes = L.vpr_head_train_workspace_bytes(B, D, hidden, n_out)
+    if nbytes == 0:
+        raise RuntimeError(f"head_train_step: unsupported shape B={B} D={D} hidden={hidden} n_out={n_out} "
+                           "(need 1 <= B <= 64, D % 16 == 0, hidden % 32 == 0, n_out <= 8)")
+    ws = workspace("head_train", nbytes, X.device)
+    st = L.vpr_head_train_step(_ptr(X), X.stride(0), _ptr(idx), _ptr(Y), Y.stride(0), B, D, hidden, n_out,
+                               _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(m), _ptr(v), int(step), float(lr),
+                               float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _ptr(loss_out),
+                               _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_head_train_step")
+    for t in (W1, b1, W2, b2, m, v):          # written behind PyTorch's back: version-keyed caches (pose-head weight planes) must see it
+        torch.autograd.graph.increment_version(t)
+
+
 def ln_meanpool_head(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                      Wh: Optional[torch.Tensor] = None, bh: Optional[torch.Tensor] = None,
                      sincos_offset: int = -1, want_pooled: bool = True
