@@ -141,6 +141,43 @@ def pmc_traffic(summary: str, kernel: str):
     return None, None
 
 
+def head_train_row(dev, hbm) -> dict:
+    import torch.nn as nn
+    from vpr_amd import ops
+    D, hidden, n_out, Bt, N = D_DESC, 512, 2, 16, 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.nn.functional.normalize(torch.randn(N, D, device=dev, generator=g), dim=1)
+    Y = torch.randn(N, n_out, device=dev, generator=g)
+    order = torch.randperm(N, device=dev, generator=g).to(torch.int32)
+    torch.manual_seed(5)
+    th = nn.Sequential(nn.Linear(D, hidden), nn.ReLU(), nn.Linear(hidden, n_out)).to(dev)
+    W = [p.detach().clone() for p in (th[0].weight, th[0].bias, th[2].weight, th[2].bias)]
+    m, v = ops.head_train_state(W[0], W[2])
+    cnt = [1]
+
+    def hip_epoch():
+        ops.head_train_epoch(X, Y, order, Bt, *W, m, v, cnt[0])
+        cnt[0] += N // Bt
+
+    ms = _avg_ms(hip_epoch, n=10, warm=2) / (N // Bt)
+    opt = torch.optim.AdamW(th.parameters(), lr=1e-5)
+    ol = order.long()
+
+    def torch_epoch():
+        for lo in range(0, 16 * Bt, Bt):
+            idx = ol[lo:lo + Bt]
+            loss = nn.functional.mse_loss(th(X[idx]), Y[idx])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+    ms_t = _avg_ms(torch_epoch, n=5, warm=1) / 16
+    by = 7 * hidden * D * 4 + 2 * Bt * D * 4
+    return dict(entry="vpr_head_train_epoch (per batch: forward, MSELoss, backward, AdamW — three launches)",
+                shape=f"B={Bt} D={D} hidden={hidden} n_out={n_out} f32", torch_autograd_adamw_ms=ms_t, speedup_vs_torch=ms_t / ms,
+                **hbm(by, ms))
+
+
 def kernel_rows(dev, ext, head, images, shard_bf16, a, salad_step_ms=None) -> dict:
     """Roofline rows of the other hand-written stages (BASELINE configs 2, 4, 5), each timed on its own after the timed
     region: algorithmic FLOPs / bytes over the average device time of the whole entry point."""
@@ -187,6 +224,10 @@ def kernel_rows(dev, ext, head, images, shard_bf16, a, salad_step_ms=None) -> di
         rows[f"ln_meanpool_head_T{T}"] = dict(entry="vpr_ln_meanpool_head", shape=f"B=256 T={T} H=1024 bf16, n_out=4 (sin,cos unit)",
                                               **hbm(xs.numel() * 2, ms))
         del xs
+    # head-only fine-tuning step on cached descriptors: the reference's head (8448 -> 512 -> 2) at its batch
+    # size 16 (dinov2salad_finetuning.py:29-31,89,95-96); one epoch-call of 64 batches per sample; PyTorch autograd + AdamW on
+    # the same GPU timed beside it (what the reference's loop runs per batch once the frozen backbone is taken out)
+    rows["head_train_step"] = head_train_row(dev, hbm)
     # whole bf16 kNN call on the bench gallery (config 3 on one GPU) + the same retrieval replayed from a HIP graph
     if shard_bf16 is not None:
         N = shard_bf16.shape[0]

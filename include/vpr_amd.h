@@ -47,7 +47,7 @@ int vpr_abi_version(void);
 /* Tuning switches (process-wide A/B knobs; names = the VPR_* environment variables read at load: VPR_KNN_VARIANT,
  * VPR_KNN_GEMM_MIN_B, VPR_KNN_GEMM_KSPLIT, VPR_KNN_FP8_GEMM256, VPR_GEMM_NT_STAGES, VPR_GEMM_GROUP_VARIANT,
  * VPR_ATTN_VARIANT, VPR_LN_ROWS, VPR_POSE_KS, VPR_SKINNY_NW, VPR_SKINNY_MBW, VPR_SALAD_VARIANT, VPR_POSE_VARIANT,
- * VPR_LNHEAD_VARIANT, VPR_GEMM256_DEPTH).  vpr_tuning_set: unset != 0 restores "not set".  vpr_tuning_get: 0 and *value, 1 if the
+ * VPR_LNHEAD_VARIANT, VPR_GEMM256_DEPTH, VPR_HEAD_TRAIN_VARIANT).  vpr_tuning_set: unset != 0 restores "not set".  vpr_tuning_get: 0 and *value, 1 if the
  * switch is not set, VPR_ERR_INVALID_ARG for an unknown name.  Not for production code paths: no call may be in
  * flight on another thread while a switch changes. */
 int vpr_tuning_set(const char* name, int value, int unset);
@@ -359,6 +359,16 @@ int vpr_head_train_step(const float* X, long long x_stride, const int* idx, cons
                         int B, int D, int hidden, int n_out, float* W1, float* b1, float* W2, float* b2,
                         float* m, float* v, int step, double lr, double beta1, double beta2, double eps,
                         double weight_decay, float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+/* A whole pass in one call: batches order[0:bs], order[bs:2bs], ... of the n rows listed in `order` (device int32; the last
+ * batch may be short, as DataLoader's default keeps it: dinov2salad_finetuning.py:89), steps first_step, first_step + 1, ...;
+ * losses [ceil(n / batch_size)] (device, may be NULL) receives the batch losses (their mean is the reference's epoch figure,
+ * :126-128).  3 * ceil(n / batch_size) launches are enqueued; nothing waits for the GPU.  The workspace must hold
+ * vpr_head_train_workspace_bytes(min(batch_size, n), ...) bytes.  Arguments are validated before the first launch. */
+int vpr_head_train_epoch(const float* X, long long x_stride, const int* order, int n, int batch_size,
+                         const float* Y, long long y_stride, int D, int hidden, int n_out,
+                         float* W1, float* b1, float* W2, float* b2, float* m, float* v, int first_step,
+                         double lr, double beta1, double beta2, double eps, double weight_decay,
+                         float* losses, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh

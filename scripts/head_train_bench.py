@@ -64,13 +64,21 @@ for (D, hidden, n_out, B) in [(8448, 512, 2, 16), (8448, 512, 2, 64), (8448, 102
         loss.backward()
         opt_f.step()
 
+    def hip_epoch(i):          # 64 batches per library call
+        b = (i * 64) % (nb - 64 + 1) if nb > 64 else 0
+        k = min(64, nb)
+        ops.head_train_epoch(X, Y, perm[b * B:(b + k) * B], B, *W, m, v, cnt[0] + 1)
+        cnt[0] += k
+
     g_hip, w_hip = time_steps(hip_step, 300)
+    g_ep, w_ep = time_steps(hip_epoch, 12)
+    g_ep, w_ep = g_ep / min(64, nb), w_ep / min(64, nb)
     g_t, w_t = time_steps(torch_step, 100)
     g_tf, w_tf = time_steps(torch_fused_step, 100)
     alg = 7 * hidden * D * 4 + 2 * B * D * 4
-    row = {"shape": f"D={D} hidden={hidden} n_out={n_out} B={B}", "hip_us_per_step": round(g_hip, 2), "hip_host_us_per_step": round(w_hip, 2),
+    row = {"shape": f"D={D} hidden={hidden} n_out={n_out} B={B}", "hip_us_per_step": round(g_hip, 2), "hip_host_us_per_step": round(w_hip, 2), "hip_epoch_call_us_per_step": round(g_ep, 2), "hip_epoch_call_host_us_per_step": round(w_ep, 2),
            "torch_autograd_adamw_us_per_step": round(g_t, 2), "torch_autograd_fused_adamw_us_per_step": round(g_tf, 2),
-           "speedup_vs_torch": round(min(g_t, g_tf) / g_hip, 2), "algorithmic_bytes": alg,
-           "achieved_GBps": round(alg / g_hip / 1e3, 1), "frac_of_8TBps": round(alg / g_hip / 1e3 / 8000, 3)}
+           "speedup_vs_torch": round(min(g_t, g_tf) / g_ep, 2), "algorithmic_bytes": alg,
+           "achieved_GBps": round(alg / g_ep / 1e3, 1), "frac_of_8TBps": round(alg / g_ep / 1e3 / 8000, 3)}
     rows.append(row)
     print(json.dumps(row), flush=True)

@@ -215,3 +215,23 @@ def test_finetune_head_hip_engine_equals_torch_engine_and_writes_the_reference_c
         assert st[k]["exp_avg"].shape == ref["exp_avg"].shape
         scale = float(ref["exp_avg"].abs().max())
         assert float((st[k]["exp_avg"].cpu() - ref["exp_avg"].cpu()).abs().max()) <= 1e-4 * scale
+
+
+def test_head_train_epoch_equals_the_same_steps_one_by_one():
+    """vpr_head_train_epoch == vpr_head_train_step per batch (same launches): bitwise, ragged last batch included."""
+    D, hidden, n_out, N, bs = 8448, 512, 2, 70, 16
+    head = _head(D, hidden, n_out, 12)
+    X, Y = _data(N, D, n_out, 13)
+    order = np.random.default_rng(14).permutation(N)
+    batches = [order[lo:lo + bs] for lo in range(0, N, bs)]
+    params, m, v, losses = _run_hip(head, X, Y, batches, 1e-4)
+    W = _gpu_params(head)
+    m2, v2 = ops.head_train_state(W[0], W[2])
+    ver = W[0]._version
+    l2 = ops.head_train_epoch(X.to(DEV), Y.to(DEV), torch.as_tensor(order, dtype=torch.int32, device=DEV), bs, *W, m2, v2, 1, lr=1e-4)
+    assert W[0]._version > ver
+    for p, q in zip(params, W):
+        assert torch.equal(p, q)
+    assert torch.equal(m, m2) and torch.equal(v, v2) and np.array_equal(losses, l2.cpu().numpy())
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        ops.head_train_epoch(X.to(DEV), Y.to(DEV), torch.as_tensor(order, dtype=torch.int32, device=DEV), 65, *W, m2, v2, 1)

@@ -68,7 +68,7 @@ inline int launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t
 enum TuneOpt {
   TUNE_KNN_VARIANT = 0, TUNE_KNN_GEMM_MIN_B, TUNE_KNN_GEMM_KSPLIT, TUNE_KNN_FP8_GEMM256, TUNE_GEMM_NT_STAGES,
   TUNE_GEMM_GROUP_VARIANT, TUNE_ATTN_VARIANT, TUNE_LN_ROWS, TUNE_POSE_KS, TUNE_SKINNY_NW, TUNE_SKINNY_MBW,
-  TUNE_SALAD_VARIANT, TUNE_POSE_VARIANT, TUNE_LNHEAD_VARIANT, TUNE_GEMM256_DEPTH, TUNE_COUNT
+  TUNE_SALAD_VARIANT, TUNE_POSE_VARIANT, TUNE_LNHEAD_VARIANT, TUNE_GEMM256_DEPTH, TUNE_HEAD_TRAIN_VARIANT, TUNE_COUNT
 };
 constexpr int TUNE_UNSET = -2147483647 - 1;
 int tune(TuneOpt o);

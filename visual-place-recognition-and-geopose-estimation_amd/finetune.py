@@ -158,16 +158,12 @@ class _HipHeadTrainer:
         self.step = 0
 
     def epoch(self, perm: torch.Tensor, batch_size: int) -> torch.Tensor:
-        """One pass in the order `perm` (ragged last batch kept, as DataLoader's default does: :89).  Returns the batch losses
-        (device tensor; nothing here waits for the GPU)."""
+        """One pass in the order `perm` (a permutation of the cached rows, built by the caller; ragged last batch kept, as
+        DataLoader's default does: :89).  Returns the batch losses (device tensor; nothing here waits for the GPU)."""
         perm32 = perm.to(device=self.X.device, dtype=torch.int32).contiguous()
-        n = perm32.numel()
-        nb = (n + batch_size - 1) // batch_size
-        losses = torch.empty(nb, dtype=torch.float32, device=self.X.device)
-        for i in range(nb):
-            self.step += 1
-            self.ops.head_train_step(self.X, self.Y, perm32[i * batch_size:(i + 1) * batch_size], self.W1, self.b1, self.W2,
-                                     self.b2, self.m, self.v, self.step, loss_out=losses[i:i + 1], **self.hyper)
+        losses = self.ops.head_train_epoch(self.X, self.Y, perm32, batch_size, self.W1, self.b1, self.W2, self.b2, self.m, self.v,
+                                           self.step + 1, **self.hyper)
+        self.step += losses.numel()
         return losses
 
     def export_optimizer_state(self) -> None:

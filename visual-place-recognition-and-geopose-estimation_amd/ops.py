@@ -652,14 +652,7 @@ def head_train_state_views(buf: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor
     return buf[:o1].view(hidden, D), buf[o1:o2], buf[o2:o3].view(n_out, hidden), buf[o3:o3 + n_out]
 
 
-def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor], W1: torch.Tensor, b1: torch.Tensor,
-                    W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-5,
-                    betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                    loss_out: Optional[torch.Tensor] = None) -> None:
-    """One batch of head-only fine-tuning on cached descriptors (vpr_head_train_step): forward, MSELoss, backward and
-    AdamW update of Linear(D,hidden)-ReLU-Linear(hidden,n_out), in place on W1 / b1 / W2 / b2 / m / v.
-    X [rows, D] f32, Y [rows, n_out] f32, idx [B] int32 (rows of the batch; None = all rows of X in order).  loss_out: a
-    one-element f32 tensor (e.g. losses[i:i+1]) that receives the batch loss.  No host synchronisation."""
+def _head_train_check(X, Y, W1, b1, W2, b2, m, v):
     _need(X, torch.float32, "X", 2)
     _need(Y, torch.float32, "Y", 2)
     _need(W1, torch.float32, "W1", 2)
@@ -672,15 +665,55 @@ def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor
     n_out = W2.shape[0]
     if X.shape[1] != D or Y.shape[0] != X.shape[0] or Y.shape[1] != n_out or b1.numel() != hidden or W2.shape[1] != hidden \
             or b2.numel() != n_out:
-        raise RuntimeError("head_train_step: inconsistent shapes")
+        raise RuntimeError("head_train: inconsistent shapes")
+    if m.numel() != _lib.lib().vpr_head_train_state_floats(D, hidden, n_out) or v.numel() != m.numel():
+        raise RuntimeError("head_train: moment buffers must hold vpr_head_train_state_floats() floats (ops.head_train_state)")
+    return D, hidden, n_out
+
+
+def head_train_epoch(X: torch.Tensor, Y: torch.Tensor, order: torch.Tensor, batch_size: int, W1: torch.Tensor, b1: torch.Tensor,
+                     W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, first_step: int, lr: float = 1e-5,
+                     betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2) -> torch.Tensor:
+    """One pass over the rows listed in `order` (int32, device) in batches of `batch_size` (vpr_head_train_epoch: the whole
+    launch sequence enqueued by ONE library call).  Returns the batch losses [ceil(n / batch_size)] (device tensor; nothing
+    waits for the GPU).  The caller guarantees 0 <= order < X.shape[0]: the kernels gather rows by these indices unchecked."""
+    D, hidden, n_out = _head_train_check(X, Y, W1, b1, W2, b2, m, v)
+    _need(order, torch.int32, "order", 1)
+    n = order.numel()
+    if n < 1 or batch_size < 1:
+        raise RuntimeError("head_train_epoch: empty pass")
+    L = _lib.lib()
+    nbytes = L.vpr_head_train_workspace_bytes(min(batch_size, n), D, hidden, n_out)
+    if nbytes == 0:
+        raise RuntimeError(f"head_train_epoch: unsupported shape B={min(batch_size, n)} D={D} hidden={hidden} n_out={n_out} "
+                           "(need 1 <= B <= 64, D % 16 == 0, hidden % 32 == 0, n_out <= 8)")
+    ws = workspace("head_train", nbytes, X.device)
+    losses = torch.empty((n + batch_size - 1) // batch_size, dtype=torch.float32, device=X.device)
+    st = L.vpr_head_train_epoch(_ptr(X), X.stride(0), _ptr(order), n, int(batch_size), _ptr(Y), Y.stride(0), D, hidden, n_out,
+                                _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(m), _ptr(v), int(first_step), float(lr),
+                                float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _ptr(losses),
+                                _ptr(ws), ws.numel(), _stream())
+    _lib.check(st, "vpr_head_train_epoch")
+    for t in (W1, b1, W2, b2, m, v):
+        torch.autograd.graph.increment_version(t)
+    return losses
+
+
+def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor], W1: torch.Tensor, b1: torch.Tensor,
+                    W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-5,
+                    betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                    loss_out: Optional[torch.Tensor] = None) -> None:
+    """One batch of head-only fine-tuning on cached descriptors (vpr_head_train_step): forward, MSELoss, backward and
+    AdamW update of Linear(D,hidden)-ReLU-Linear(hidden,n_out), in place on W1 / b1 / W2 / b2 / m / v.
+    X [rows, D] f32, Y [rows, n_out] f32, idx [B] int32 (rows of the batch; None = all rows of X in order).  loss_out: a
+    one-element f32 tensor (e.g. losses[i:i+1]) that receives the batch loss.  No host synchronisation."""
+    D, hidden, n_out = _head_train_check(X, Y, W1, b1, W2, b2, m, v)
     if idx is not None:
         _need(idx, torch.int32, "idx", 1)
         B = idx.numel()
     else:
         B = X.shape[0]
     L = _lib.lib()
-    if m.numel() != L.vpr_head_train_state_floats(D, hidden, n_out) or v.numel() != m.numel():
-        raise RuntimeError("head_train_step: moment buffers must hold vpr_head_train_state_floats() floats (ops.head_train_state)")
     if loss_out is not None:
         _need(loss_out, torch.float32, "loss_out")
         if loss_out.numel() != 1:
