@@ -14,6 +14,8 @@ def test_every_op_is_registered_with_a_schema():
         assert schema.startswith(f"vpr::{name}("), schema
     assert "!)? uncertified" in str(torch.ops.vpr.knn_topk.default._schema)                  # the one mutated argument
     assert "Tensor? W1" in str(torch.ops.vpr.pose_head.default._schema)
+    sch = str(torch.ops.vpr.head_train_epoch.default._schema)                                # six tensors updated in place
+    assert sch.count("!") == 6 and all(f"!) {n}" in sch for n in ("W1", "b1", "W2", "b2", "m", "v")), sch
 
 
 def test_ops_refuse_cpu_tensors_through_the_dispatcher():
@@ -56,6 +58,12 @@ def test_fake_implementations_give_shapes_and_dtypes():
         assert pooled.shape == (256, 1024) and out.shape == (256, 4)
         pooled, out = torch.ops.vpr.ln_meanpool_head(mk(8, 144, 1024), mk(1024, dtype=f32), mk(1024, dtype=f32), 1e-5, None, None, -1)
         assert pooled.shape == (8, 1024) and out.shape == (8, 0)
+        W1, W2 = mk(512, 8448, dtype=f32), mk(2, 512, dtype=f32)
+        n_state = 512 * 8448 + 512 + 2 * 512 + 2
+        losses = torch.ops.vpr.head_train_epoch(mk(6378, 8448, dtype=f32), mk(6378, 2, dtype=f32), mk(6378, dtype=torch.int32), 16,
+                                                W1, mk(512, dtype=f32), W2, mk(2, dtype=f32), mk(n_state, dtype=f32),
+                                                mk(n_state, dtype=f32), 1, 1e-5, 0.9, 0.999, 1e-8, 1e-2)
+        assert losses.shape == (399,) and losses.dtype == f32            # ceil(6378 / 16): the reference's batches per epoch
 
 
 def test_modules_trace_with_fake_tensors():

@@ -141,7 +141,7 @@ class _HipHeadTrainer:
     only when a checkpoint wants `optimizer.state_dict()` (the reference's checkpoint dict, :130-135)."""
 
     def __init__(self, head: nn.Module, X: torch.Tensor, Y: torch.Tensor, opt: torch.optim.Optimizer):
-        from . import ops
+        from . import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.vpr.*)
         lin = [m for m in head if isinstance(m, nn.Linear)]
         rest = [m for m in head if not isinstance(m, (nn.Linear, nn.ReLU))]
         if len(lin) != 2 or rest or not isinstance(head[1], nn.ReLU):
@@ -161,8 +161,10 @@ class _HipHeadTrainer:
         """One pass in the order `perm` (a permutation of the cached rows, built by the caller; ragged last batch kept, as
         DataLoader's default does: :89).  Returns the batch losses (device tensor; nothing here waits for the GPU)."""
         perm32 = perm.to(device=self.X.device, dtype=torch.int32).contiguous()
-        losses = self.ops.head_train_epoch(self.X, self.Y, perm32, batch_size, self.W1, self.b1, self.W2, self.b2, self.m, self.v,
-                                           self.step + 1, **self.hyper)
+        h = self.hyper              # through the operator layer: the dispatcher sees the six in-place updates (version counters)
+        losses = torch.ops.vpr.head_train_epoch(self.X, self.Y, perm32, batch_size, self.W1, self.b1, self.W2, self.b2, self.m,
+                                                self.v, self.step + 1, h["lr"], h["betas"][0], h["betas"][1], h["eps"],
+                                                h["weight_decay"])
         self.step += losses.numel()
         return losses
 

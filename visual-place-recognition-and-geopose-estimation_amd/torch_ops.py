@@ -7,6 +7,7 @@ that seam, so the HIP hot path is visible to PyTorch's dispatcher like any other
     torch.ops.vpr.salad_aggregate / salad_aggregate_split / salad_aggregate_f32
     torch.ops.vpr.knn_topk / knn_topk_fp8 / topk_merge
     torch.ops.vpr.pose_head / ln_meanpool_head
+    torch.ops.vpr.head_train_epoch                     (head-only fine-tuning pass; mutates parameters and AdamW moments)
 
 Each op has
   * a CUDA(HIP) implementation = the ctypes wrapper of `vpr_amd.ops` (same validation, same stream, same workspaces;
@@ -176,5 +177,22 @@ def _(x, gamma, beta, eps, Wh, bh, sincos_offset):
     return x.new_empty((B, H), dtype=torch.float32), x.new_empty((B, 0 if Wh is None else Wh.shape[0]), dtype=torch.float32)
 
 
-OPS = ("salad_aggregate", "salad_aggregate_split", "salad_aggregate_f32", "knn_topk", "knn_topk_fp8", "quantize_fp8_rows",
+# ------------------------------------------------------------------------------------------------- head fine-tuning
+@torch.library.custom_op("vpr::head_train_epoch", mutates_args=("W1", "b1", "W2", "b2", "m", "v"))
+def head_train_epoch(X: Tensor, Y: Tensor, order: Tensor, batch_size: int, W1: Tensor, b1: Tensor, W2: Tensor, b2: Tensor,
+                     m: Tensor, v: Tensor, first_step: int, lr: float, beta1: float, beta2: float, eps: float,
+                     weight_decay: float) -> Tensor:
+    """One pass of head-only fine-tuning over the cached descriptor rows listed in `order` (int32), batches of `batch_size`:
+    forward, MSELoss, backward and AdamW of Linear(D,hidden)-ReLU-Linear(hidden,n_out) per batch, IN PLACE on the
+    parameters and on the moment buffers (ops.head_train_state).  Returns the batch losses.  dinov2salad_finetuning.py:113-128
+    (one epoch of the loop) on descriptors computed once.  vpr_head_train_epoch."""
+    return ops.head_train_epoch(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, (beta1, beta2), eps, weight_decay)
+
+
+@head_train_epoch.register_fake
+def _(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, beta1, beta2, eps, weight_decay):
+    return X.new_empty(((order.shape[0] + batch_size - 1) // batch_size,), dtype=torch.float32)
+
+
+OPS = ("head_train_epoch", "salad_aggregate", "salad_aggregate_split", "salad_aggregate_f32", "knn_topk", "knn_topk_fp8", "quantize_fp8_rows",
        "topk_merge", "pose_head", "ln_meanpool_head")
