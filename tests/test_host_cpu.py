@@ -234,8 +234,10 @@ def test_finetune_head_on_cached_descriptors(tmp_path):
     model = modules.DINOv2RegressionModel(nn.Identity())
     ref_head = nn.Sequential(nn.Linear(8448, 512), nn.ReLU(), nn.Linear(512, 2))
     ref_head.load_state_dict(model.regressor.state_dict())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):                 # the default engine is the HIP training step
+        finetune.finetune_head(model, desc, labels, epochs=1, log=lambda s: None)
     out = finetune.finetune_head(model, desc, labels, epochs=3, batch_size=16, lr=1e-3, save_dir=str(tmp_path),
-                                 val=(desc[:8], labels[:8]), seed=5, log=lambda s: None)
+                                 val=(desc[:8], labels[:8]), seed=5, log=lambda s: None, engine="torch")
     # reference-style loop (dinov2salad_finetuning.py:95-128) on the same data and batch order
     mean, std = labels.mean(0), labels.std(0)
     y = torch.from_numpy(((labels - mean) / std).astype(np.float32))

@@ -12,7 +12,7 @@ head's training step itself (forward, MSELoss, backward, AdamW: dinov2salad_fine
 the HIP entry point vpr_head_train_step — three launches per batch, no host synchronisation inside an
 epoch, the 17 MB gradient of W1 never written to memory — checked against oracle/finetune.py (pinned to
 torch autograd + torch.optim.AdamW).  engine="torch" keeps the PyTorch-autograd loop (CPU tensors, or an
-explicit A/B on the GPU: scripts/head_train_bench.py).
+explicit A/B on the GPU: scripts/head_train_bench.py) and is never chosen silently.
 """
 from __future__ import annotations
 
@@ -64,16 +64,18 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
     """Trains model.regressor on cached descriptors.  labels [N,2] raw (lat, lon); they are
     standardised with a scaler fitted here (returned and, if save_dir, dumped as JSON).
     val = (val_descriptors, val_labels_raw) for the per-epoch de-normalised report.
-    engine: "hip" = vpr_head_train_step (GPU descriptors; raises if the head is not Linear-ReLU-Linear of a supported
-    shape), "torch" = PyTorch autograd + torch.optim.AdamW, "auto" = "hip" for GPU descriptors, "torch" for CPU ones.
+    engine: "hip" (= "auto", the default) = vpr_head_train_epoch — needs the descriptors on the GPU and a Linear-ReLU-Linear head
+    of a supported shape, and RAISES otherwise: there is no silent fallback; "torch" = the same loop as PyTorch autograd +
+    torch.optim.AdamW, only when asked for by name (the CPU tests of the host logic, the A/B of scripts/head_train_bench.py).
     Both engines draw the same batches (same seeded permutations) and write the same checkpoint format."""
     dev = descriptors.device
     if engine not in ("auto", "hip", "torch"):
         raise ValueError(f"finetune_head: unknown engine {engine!r}")
     if engine == "auto":
-        engine = "hip" if descriptors.is_cuda else "torch"
+        engine = "hip"
     if engine == "hip" and not descriptors.is_cuda:
-        raise RuntimeError("finetune_head: engine='hip' needs the descriptors on the GPU (there is no CPU fallback)")
+        raise RuntimeError("finetune_head: the training step is a HIP kernel and needs the descriptors on the GPU (there is no CPU "
+                           "fallback); engine='torch' runs the PyTorch-autograd loop instead, on any device")
     scaler = LatLonScaler.fit(labels)
     y = torch.from_numpy(scaler.transform(np.asarray(labels, dtype=np.float64)).astype(np.float32)).to(dev)
     head = model.regressor.to(dev).float()
