@@ -47,7 +47,7 @@ int vpr_abi_version(void);
 /* Tuning switches (process-wide A/B knobs; names = the VPR_* environment variables read at load: VPR_KNN_VARIANT,
  * VPR_KNN_GEMM_MIN_B, VPR_KNN_GEMM_KSPLIT, VPR_KNN_FP8_GEMM256, VPR_GEMM_NT_STAGES, VPR_GEMM_GROUP_VARIANT,
  * VPR_ATTN_VARIANT, VPR_LN_ROWS, VPR_POSE_KS, VPR_SKINNY_NW, VPR_SKINNY_MBW, VPR_SALAD_VARIANT, VPR_POSE_VARIANT,
- * VPR_LNHEAD_VARIANT, VPR_GEMM256_DEPTH, VPR_HEAD_TRAIN_VARIANT).  vpr_tuning_set: unset != 0 restores "not set".  vpr_tuning_get: 0 and *value, 1 if the
+ * VPR_LNHEAD_VARIANT, VPR_GEMM256_DEPTH, VPR_HEAD_TRAIN_VARIANT, VPR_GEMM256_STAGGER).  vpr_tuning_set: unset != 0 restores "not set".  vpr_tuning_get: 0 and *value, 1 if the
  * switch is not set, VPR_ERR_INVALID_ARG for an unknown name.  Not for production code paths: no call may be in
  * flight on another thread while a switch changes. */
 int vpr_tuning_set(const char* name, int value, int unset);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 static const char* const kTuneNames[TUNE_COUNT] = {
     "VPR_KNN_VARIANT", "VPR_KNN_GEMM_MIN_B", "VPR_KNN_GEMM_KSPLIT", "VPR_KNN_FP8_GEMM256", "VPR_GEMM_NT_STAGES",
     "VPR_GEMM_GROUP_VARIANT", "VPR_ATTN_VARIANT", "VPR_LN_ROWS", "VPR_POSE_KS", "VPR_SKINNY_NW", "VPR_SKINNY_MBW",
-    "VPR_SALAD_VARIANT", "VPR_POSE_VARIANT", "VPR_LNHEAD_VARIANT", "VPR_GEMM256_DEPTH", "VPR_HEAD_TRAIN_VARIANT"};
+    "VPR_SALAD_VARIANT", "VPR_POSE_VARIANT", "VPR_LNHEAD_VARIANT", "VPR_GEMM256_DEPTH", "VPR_HEAD_TRAIN_VARIANT", "VPR_GEMM256_STAGGER"};
 struct TuneTable {
   int v[TUNE_COUNT];
   TuneTable() {

@@ -144,11 +144,25 @@ __device__ __forceinline__ void g2_mainloop(const GemmProblem& pr, char* smem, G
   for (int h = 0; h < 4; ++h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) src[h][j] += (long long)k_lo * 128;
-  auto issue = [&](int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1 (kt clamped: dummy tail)
+  // K walk: step kt of this tile reads K-tile (kt + koff) mod nk.  With koff = 0 every tile that shares an operand panel asks
+  // the L2 for the same lines in the same microsecond; a per-tile rotation spreads those requests over time (Tensile calls
+  // the same idea StaggerU).  A sum is a sum: only the f32 accumulation order of a tile changes, and it is fixed per tile.
+  int koff = 0;
+  switch (pr.kstagger) {
+    case 1: koff = tn; break;                            // tiles sharing an A panel one K-tile apart
+    case 2: koff = tm + tn; break;                       // neighbours in both directions apart
+    case 3: koff = (tm & 3) * 4 + (tn & 3); break;
+    case 4: koff = tm & 3; break;                        // tiles sharing a W panel apart
+    case 5: koff = 2 * tn + (tm & 1); break;
+    default: break;
+  }
+  koff %= nk;
+  auto issue = [&](int h, int kt) {   // half-tile h of step kt -> buffer kt & 1 (kt clamped: dummy tail)
     const int kc = kt < nk ? kt : nk - 1;
     char* base = smem + (kc & 1) * G2_BUF_BYTES;
+    const int kk = kc + koff < nk ? kc + koff : kc + koff - nk;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(src[h][j] + kc * 128, base + dst[h][j]);
+    for (int j = 0; j < 2; ++j) glds16(src[h][j] + kk * 128, base + dst[h][j]);
   };
 
 #pragma unroll
@@ -497,6 +511,7 @@ int launch_gemm256(const GemmProblem& in, hipStream_t stream) {
   g.tiles_m = (g.M + G2_BM - 1) / G2_BM;
   g.tiles_n = (g.N + G2_BN - 1) / G2_BN;
   g.a_scale = g.w_scale = nullptr;
+  g.kstagger = tune_or(TUNE_GEMM256_STAGGER, 0);
   const int ksplit = g.ksplit > 1 ? g.ksplit : 1;
   if (ksplit > 1 && (g.bias != nullptr || g.relu || g.K / 64 < 2 * ksplit)) return VPR_ERR_UNSUPPORTED;   // slabs are linear partial sums
 #ifdef VPR_ABLATION
@@ -560,7 +575,7 @@ int launch_salad_mlps_fused(const uint16_t* X, int ldx, int group_rows, long lon
        reinterpret_cast<uintptr_t>(b2c) | reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(F)) & 15)
     return VPR_ERR_UNSUPPORTED;
   GemmProblem g{X, ldx, group_rows, group_stride, W1, C, b1, 1, nullptr, 0, 1, M, 2 * hidden, C, M / G2_BM, 2 * hidden / G2_BN,
-                nullptr, nullptr, 1, 0};
+                nullptr, nullptr, 1, 0, tune_or(TUNE_GEMM256_STAGGER, 0)};
   if ((reinterpret_cast<uintptr_t>(W2s_frag) | reinterpret_cast<uintptr_t>(W2c_frag)) & 15) return VPR_ERR_UNSUPPORTED;
   Fuse2 f{{W2s, W2c}, {W2s_frag, W2c_frag}, {b2s, b2c}, {S, F}, {m, l}, hidden};
   static PerDeviceFlag attr = {};
@@ -584,7 +599,8 @@ int launch_gemm256_fp8(const uint8_t* A, int lda, const float* a_scale, const ui
   if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C)) & 15)
     return VPR_ERR_UNSUPPORTED;
   GemmProblem g{reinterpret_cast<const uint16_t*>(A), lda, 0, 0, reinterpret_cast<const uint16_t*>(W), ldw, nullptr, 0,
-                C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale, ksplit, slab_stride};
+                C, ldc, 0, M, N, K, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, a_scale, w_scale, ksplit, slab_stride,
+                tune_or(TUNE_GEMM256_STAGGER, 0)};
   static PerDeviceFlag attr = {};
   VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(gemm256_kernel<true>), G2_LDS, attr));
   VPR_TRY_LAUNCH(launch_kernel(gemm256_kernel<true>, dim3(g.tiles_m * g.tiles_n, ksplit), dim3(512), G2_LDS, stream, g));

@@ -20,6 +20,7 @@ struct GemmProblem {
   void* C; int ldc; int out_is_bf16; int M, N, K; int tiles_m, tiles_n;
   const float* a_scale; const float* w_scale;       // gemm256 fp8 form only (per-row scales of A and W); null otherwise
   int ksplit; long long slab_stride;                // gemm256 split-K: K slices (0 / 1 = none); slice z writes C + z * slab_stride elements
+  int kstagger;                                     // gemm256: order in which a tile walks its K-tiles (0 = 0, 1, 2, ...; see g2_mainloop)
 };
 constexpr int GEMM_MAX_GROUP = 3;
 int launch_gemm_nt_group(const GemmProblem* probs, int count, hipStream_t stream);
@@ -68,7 +69,7 @@ inline int launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t
 enum TuneOpt {
   TUNE_KNN_VARIANT = 0, TUNE_KNN_GEMM_MIN_B, TUNE_KNN_GEMM_KSPLIT, TUNE_KNN_FP8_GEMM256, TUNE_GEMM_NT_STAGES,
   TUNE_GEMM_GROUP_VARIANT, TUNE_ATTN_VARIANT, TUNE_LN_ROWS, TUNE_POSE_KS, TUNE_SKINNY_NW, TUNE_SKINNY_MBW,
-  TUNE_SALAD_VARIANT, TUNE_POSE_VARIANT, TUNE_LNHEAD_VARIANT, TUNE_GEMM256_DEPTH, TUNE_HEAD_TRAIN_VARIANT, TUNE_COUNT
+  TUNE_SALAD_VARIANT, TUNE_POSE_VARIANT, TUNE_LNHEAD_VARIANT, TUNE_GEMM256_DEPTH, TUNE_HEAD_TRAIN_VARIANT, TUNE_GEMM256_STAGGER, TUNE_COUNT
 };
 constexpr int TUNE_UNSET = -2147483647 - 1;
 int tune(TuneOpt o);
