@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
     const float* __restrict__ feats,    // [NSLAB][B, n, l]
     const float* __restrict__ tokfeat,  // [B, t]
     long long slab_rows, float dustbin, int iters,
-    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int* __restrict__ counters) {
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int* __restrict__ counters, int rows_per_xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Mx = reinterpret_cast<float*>(smem);        // [65][257] raw scores; later the two P planes
   uint16_t* Phi = reinterpret_cast<uint16_t*>(smem);      // [64][SA_PLD] bf16: hi plane of P (16-byte aligned rows)
@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256, 1) void sinkhorn_aggregate_kernel(
   float* be = al + 68;                               // [256] beta
   float* ssq = be + SA_N;                            // [4][64]
   float* red = ssq + 4 * SA_M;                       // [4]
-  const int b = NQ == 4 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  // rows_per_xcd > 0 (A/B, VPR_SALAD_VARIANT=4): workgroup i runs on XCD i & 7 (round-robin dispatch); take the image whose
+  // score / feature slabs the MLP kernel's tiles wrote from THAT XCD (gemm256's tile map gives XCD x the row tiles
+  // [x * rows_per_xcd, (x + 1) * rows_per_xcd)), in case its L2 still holds them
+  const int b = NQ == 4 ? (int)(blockIdx.x >> 2)
+                        : rows_per_xcd > 0 ? rows_per_xcd * (int)(blockIdx.x & 7) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int qd = NQ == 4 ? (int)(blockIdx.x & 3) : 0;          // which quarter of the cluster dims this workgroup aggregates
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int D_OUT = SA_T + SA_L * SA_M;
@@ -420,12 +424,13 @@ int launch_sinkhorn_aggregate(const float* scores, const float* feats, const flo
   // HBM-bound (5.9 us to issue the loads instead of 3.1), and the finisher's second pass over the row costs 4.2 us, which
   // eats what the quartered aggregation saves.  VPR_SALAD_VARIANT=3 selects it (A/B); it needs the zeroed counter area.
   const bool quarters = counters != nullptr && 4 * B <= device_cu_count() && tune_or(TUNE_SALAD_VARIANT, 0) == 3;
+  const int rpx = (!quarters && nslab == 2 && B % 8 == 0 && tune_or(TUNE_SALAD_VARIANT, 0) == 4) ? B / 8 : 0;
 #define VPR_SINKHORN_LAUNCH(NS, NQV, LDS, GRID)                                                                              \
   do {                                                                                                                       \
     static PerDeviceFlag attr = {};   /* > 64 KiB of dynamic LDS needs the opt-in once per device */                         \
     VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_aggregate_kernel<NS, NQV>), LDS, attr));         \
     VPR_TRY_LAUNCH(launch_kernel((sinkhorn_aggregate_kernel<NS, NQV>), dim3(GRID), dim3(256), LDS, stream, scores, feats, tokfeat, \
-                                 nslab == 2 ? slab_rows : 0LL, dustbin, iters, out_f32, out_bf16, counters));                 \
+                                 nslab == 2 ? slab_rows : 0LL, dustbin, iters, out_f32, out_bf16, counters, rpx));            \
   } while (0)
   if (quarters) {
     if (nslab == 2) VPR_SINKHORN_LAUNCH(2, 4, SINKHORN_LDS_Q, 4 * B); else VPR_SINKHORN_LAUNCH(1, 4, SINKHORN_LDS_Q, 4 * B);
