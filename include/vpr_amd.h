@@ -348,17 +348,23 @@ int vpr_pose_head_fused(const float* x, const uint16_t* W1_hi_frag, const uint16
  * [W1 | b1 | W2 | b2], zero before step 1, updated in place.  step = 1, 2, ... (number of this update: bias corrections).
  * Hyper-parameters are doubles, as Python holds them; every derived scalar (1 - lr*wd, lr / (1 - beta1^step), ...) is formed in
  * double and rounded to f32 once, and the update follows torch.optim.AdamW's order of operations.
+ * loss_kind: VPR_LOSS_MSE (nn.MSELoss, the script above) or VPR_LOSS_HUBER with huber_delta > 0 (nn.HuberLoss(delta): the loss of
+ * dinov2salad_finetuning_2.py:154 / swin_transformer/swin_attempt_2.py:158 — 0.5 d^2 for |d| < delta, delta (|d| - 0.5 delta) beyond;
+ * mean over the B * n_out elements); huber_delta is ignored for MSE.
  * loss_out (device, may be NULL) receives this batch's loss (before the update).  All arithmetic f32 with fixed summation
  * orders: bitwise reproducible.  The gradient of W1 is never written to memory (formed in registers, consumed by the update).
  * Requires 1 <= B <= 64, D % 16 == 0, hidden % 32 == 0, 1 <= n_out <= 8, x_stride % 4 == 0, 16-byte aligned X / W1 / m / v /
  * workspace; workspace contents are scratch.  Status codes as everywhere (VPR_ERR_UNSUPPORTED for other shapes).
  * ------------------------------------------------------------------------------------------ */
+#define VPR_LOSS_MSE 0
+#define VPR_LOSS_HUBER 1
 size_t vpr_head_train_workspace_bytes(int B, int D, int hidden, int n_out);
 long long vpr_head_train_state_floats(int D, int hidden, int n_out);
 int vpr_head_train_step(const float* X, long long x_stride, const int* idx, const float* Y, long long y_stride,
                         int B, int D, int hidden, int n_out, float* W1, float* b1, float* W2, float* b2,
                         float* m, float* v, int step, double lr, double beta1, double beta2, double eps,
-                        double weight_decay, float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+                        double weight_decay, int loss_kind, double huber_delta, float* loss_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* A whole pass in one call: batches order[0:bs], order[bs:2bs], ... of the n rows listed in `order` (device int32; the last
  * batch may be short, as DataLoader's default keeps it: dinov2salad_finetuning.py:89), steps first_step, first_step + 1, ...;
  * losses [ceil(n / batch_size)] (device, may be NULL) receives the batch losses (their mean is the reference's epoch figure,
@@ -368,7 +374,7 @@ int vpr_head_train_epoch(const float* X, long long x_stride, const int* order, i
                          const float* Y, long long y_stride, int D, int hidden, int n_out,
                          float* W1, float* b1, float* W2, float* b2, float* m, float* v, int first_step,
                          double lr, double beta1, double beta2, double eps, double weight_decay,
-                         float* losses, void* workspace, size_t workspace_bytes, void* stream);
+                         int loss_kind, double huber_delta, float* losses, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Swin pooler + linear head: pooled = mean_t LayerNorm(x[b,t,:]) ; out = Wh * pooled + bh

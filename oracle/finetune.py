@@ -2,7 +2,8 @@
 
 What it restates, per batch, of dinov2salad/dinov2salad_finetuning.py:
   :37      preds = regressor(features)                  Linear(D,hidden) -> ReLU -> Linear(hidden,n_out)   (:28-32)
-  :96,:121 loss = nn.MSELoss()(preds, targets)          mean over the B * n_out elements
+  :96,:121 loss = nn.MSELoss()(preds, targets)          mean over the B * n_out elements  (nn.HuberLoss(delta) of
+           dinov2salad_finetuning_2.py:154 / swin_attempt_2.py:158 as the second loss kind)
   :123-125 optimizer.zero_grad(); loss.backward(); optimizer.step()
   :95      torch.optim.AdamW(model.parameters(), lr=1e-5)   defaults betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2
 The backward pass is written out by hand (no autograd) and AdamW follows torch.optim's single-tensor update in its order of
@@ -42,14 +43,25 @@ def forward(st: HeadState, x: np.ndarray):
     return z, h, h @ st.W2.T + st.b2
 
 
-def loss_and_grads(st: HeadState, x: np.ndarray, y: np.ndarray):
-    """MSELoss (mean over every element) and its gradients w.r.t. (W1, b1, W2, b2)."""
+def loss_and_grads(st: HeadState, x: np.ndarray, y: np.ndarray, loss: str = "mse", huber_delta: float = 1.0):
+    """The loss (mean over every element) and its gradients w.r.t. (W1, b1, W2, b2).
+    loss = "mse": nn.MSELoss (dinov2salad_finetuning.py:96); "huber": nn.HuberLoss(delta) (dinov2salad_finetuning_2.py:154,
+    swin_transformer/swin_attempt_2.py:158): 0.5 d^2 where |d| < delta, delta (|d| - 0.5 delta) elsewhere."""
     x = np.asarray(x, dtype=st.W1.dtype)
     y = np.asarray(y, dtype=st.W1.dtype)
     z, h, o = forward(st, x)
     diff = o - y
-    loss = float(np.mean(diff * diff))
-    do = 2.0 * diff / diff.size                      # d loss / d o
+    if loss == "mse":
+        value = float(np.mean(diff * diff))
+        do = 2.0 * diff / diff.size                  # d loss / d o
+    elif loss == "huber":
+        ad = np.abs(diff)
+        inside = ad < huber_delta
+        value = float(np.mean(np.where(inside, 0.5 * diff * diff, huber_delta * (ad - 0.5 * huber_delta))))
+        do = np.where(inside, diff, huber_delta * np.sign(diff)) / diff.size
+    else:
+        raise ValueError(loss)
+    loss = value
     gW2 = do.T @ h
     gb2 = do.sum(axis=0)
     dz = (do @ st.W2) * (h > 0)                      # ReLU backward: torch masks on the OUTPUT being > 0
@@ -72,11 +84,11 @@ def adamw_update(st: HeadState, grads, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, we
         p -= (lr / bc1) * (m / denom)
 
 
-def train_step(st: HeadState, x, y, **opt) -> float:
-    """One batch: forward, MSE, backward, AdamW.  Returns the loss of the batch (before the update)."""
-    loss, grads = loss_and_grads(st, x, y)
+def train_step(st: HeadState, x, y, loss: str = "mse", huber_delta: float = 1.0, **opt) -> float:
+    """One batch: forward, loss, backward, AdamW.  Returns the loss of the batch (before the update)."""
+    value, grads = loss_and_grads(st, x, y, loss, huber_delta)
     adamw_update(st, grads, **opt)
-    return loss
+    return value
 
 
 def train_epoch(st: HeadState, X, Y, order, batch_size: int, **opt) -> float:

@@ -83,3 +83,30 @@ def test_oracle_epoch_mean_loss_and_dead_units():
     assert abs(mean - np.mean(losses)) < 1e-15
     assert np.allclose(st.W1[:4], w_dead * (1 - 1e-3 * 1e-2) ** 3, rtol=1e-14, atol=0)
     assert np.all(st.m[0][:4] == 0) and np.all(st.v[0][:4] == 0)
+
+
+@pytest.mark.parametrize("delta", [1.0, 0.25])
+def test_oracle_huber_step_equals_torch_huberloss_f64(delta):
+    """loss="huber" = nn.HuberLoss(delta) (dinov2salad_finetuning_2.py:154, swin_attempt_2.py:158), targets scaled so that
+    residuals fall on both sides of delta."""
+    D, hidden, n_out, N, bs, lr = 48, 32, 2, 30, 8, 1e-3
+    head = _torch_head(D, hidden, n_out, 7, torch.float64)
+    st = _state_from(head)
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(N, D, generator=g, dtype=torch.float64)
+    Y = torch.randn(N, n_out, generator=g, dtype=torch.float64) * 1.5
+    opt = torch.optim.AdamW(head.parameters(), lr=lr, weight_decay=0.05)
+    loss_fn = nn.HuberLoss(delta=delta)
+    outside = 0
+    for lo in list(range(0, N, bs)) * 3:
+        out = head(X[lo:lo + bs])
+        outside += int(((out - Y[lo:lo + bs]).abs() >= delta).sum())
+        loss = loss_fn(out, Y[lo:lo + bs])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lo_oracle = oft.train_step(st, X[lo:lo + bs].numpy(), Y[lo:lo + bs].numpy(), loss="huber", huber_delta=delta, lr=lr, weight_decay=0.05)
+        assert abs(lo_oracle - float(loss.detach())) <= 1e-12
+    assert outside > 10                                   # both branches of the loss were exercised
+    for p_t, p_o in zip((head[0].weight, head[0].bias, head[2].weight, head[2].bias), st.p):
+        assert np.abs(p_t.detach().numpy() - p_o).max() <= 1e-13

@@ -235,3 +235,26 @@ def test_head_train_epoch_equals_the_same_steps_one_by_one():
     assert torch.equal(m, m2) and torch.equal(v, v2) and np.array_equal(losses, l2.cpu().numpy())
     with pytest.raises(RuntimeError, match="unsupported shape"):
         ops.head_train_epoch(X.to(DEV), Y.to(DEV), torch.as_tensor(order, dtype=torch.int32, device=DEV), 65, *W, m2, v2, 1)
+
+
+@pytest.mark.parametrize("D,hidden,n_out,N,bs,steps,lr,delta", [(8448, 512, 2, 64, 16, 8, 1e-4, 1.0), (256, 64, 4, 40, 33, 6, 1e-3, 0.25)])
+def test_head_train_step_huber_loss_matches_oracle(D, hidden, n_out, N, bs, steps, lr, delta):
+    """loss="huber" (nn.HuberLoss(delta): dinov2salad_finetuning_2.py:154) with residuals on both sides of delta, and a weight
+    decay other than the default."""
+    head = _head(D, hidden, n_out, 20)
+    X, Y = _data(N, D, n_out, 21)
+    Y = Y * 1.5
+    batches = _batches(N, bs, steps, 22)
+    hyper = dict(loss="huber", huber_delta=delta, weight_decay=0.05)
+    params, m, v, losses = _run_hip(head, X, Y, batches, lr, **hyper)
+    st, ref_losses = _run_oracle(head, X, Y, batches, lr, **hyper)
+    z, h, o = oft.forward(oft.HeadState(*(p.detach().numpy() for p in (head[0].weight, head[0].bias, head[2].weight, head[2].bias))),
+                          X.numpy().astype(np.float64))
+    frac_outside = float((np.abs(o - Y.numpy()) >= delta).mean())
+    assert 0.05 < frac_outside < 0.95                     # both branches of the loss are in play
+    rel = np.abs(losses - ref_losses) / np.abs(ref_losses)
+    worst = max(float(np.abs(p.cpu().numpy().astype(np.float64) - r).max()) for p, r in zip(params, st.p))
+    print(f"\n[head_train huber delta={delta} D={D}] outside {frac_outside:.2f}; loss rel {rel.max():.1e}; params {worst / lr:.1e} lr")
+    assert rel.max() <= 2e-5 and worst <= 0.05 * lr * steps
+    with pytest.raises(RuntimeError, match="mse.*huber|loss must be"):
+        ops.head_train_step(X.to(DEV), Y.to(DEV), None, *params, m, v, 1, loss="l1")

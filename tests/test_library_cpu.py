@@ -62,14 +62,16 @@ def test_invalid_arguments_are_rejected_without_a_device(lib):
     assert lib.vpr_salad_sinkhorn_aggregate(p, p, p, 1, 100, 64, 128, 256, 1.0, 3, p, null, null) == -2
     assert lib.vpr_f32_to_bf16(null, null, 4, null) == -1
     # head-only fine-tuning step: arguments are judged before anything is launched
-    hp = (1e-5, 0.9, 0.999, 1e-8, 1e-2)
+    hp = (1e-5, 0.9, 0.999, 1e-8, 1e-2, 0, 0.0)           # lr, betas, eps, weight decay, VPR_LOSS_MSE, (delta unused)
     ws = lib.vpr_head_train_workspace_bytes(16, 64, 32, 2)
     assert ws > 0 and lib.vpr_head_train_workspace_bytes(65, 64, 32, 2) == 0 and lib.vpr_head_train_workspace_bytes(16, 60, 32, 2) == 0
     assert lib.vpr_head_train_workspace_bytes(16, 64, 48, 2) == 0 and lib.vpr_head_train_workspace_bytes(16, 64, 32, 9) == 0
     assert lib.vpr_head_train_state_floats(8448, 512, 2) == 512 * 8448 + 512 + 2 * 512 + 2
     assert lib.vpr_head_train_step(null, 64, null, null, 2, 16, 64, 32, 2, null, null, null, null, null, null, 1, *hp, null, null, 0, null) == -1
     assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 0, *hp, null, p, 4096, null) == -1        # step < 1
-    assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, 1e-5, 1.0, 0.999, 1e-8, 0.0, null, p, 4096, null) == -1   # beta1 = 1
+    assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, 1e-5, 1.0, 0.999, 1e-8, 0.0, 0, 0.0, null, p, 4096, null) == -1   # beta1 = 1
+    assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, 1e-5, 0.9, 0.999, 1e-8, 0.0, 1, 0.0, null, p, 4096, null) == -1    # Huber needs delta > 0
+    assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, 1e-5, 0.9, 0.999, 1e-8, 0.0, 2, 1.0, null, p, 4096, null) == -1    # unknown loss kind
     assert lib.vpr_head_train_step(p, 64, null, p, 2, 65, 64, 32, 2, p, p, p, p, p, p, 1, *hp, null, p, 4096, null) == -2        # B > 64
     assert lib.vpr_head_train_step(p, 62, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, *hp, null, p, 4096, null) == -1        # x_stride < D
     assert lib.vpr_head_train_step(p, 64, null, p, 2, 16, 64, 32, 2, p, p, p, p, p, p, 1, *hp, null, p, 16, null) == -3          # workspace too small

@@ -118,10 +118,12 @@ PROTOTYPES = {
     "vpr_head_train_state_floats": (c_longlong, [c_int] * 3),
     "vpr_head_train_step": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                    c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_double, c_double, c_double, c_double, c_double, c_int, c_double, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     "vpr_head_train_epoch": (c_int, [c_void_p, c_longlong, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                     c_double, c_double, c_double, c_double, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                     c_double, c_double, c_double, c_double, c_double, c_int, c_double, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     "vpr_patchify_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vpr_add_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p,
                                        c_longlong, c_int, c_void_p]),

@@ -1,6 +1,6 @@
 // head_train.hip — one optimizer step of the two-layer regression head on cached descriptors.
 //
-// vpr_head_train_step   forward, MSE loss, backward and AdamW update of Linear(D,hidden) -> ReLU -> Linear(hidden,n_out)
+// vpr_head_train_step   forward, MSE (or Huber) loss, backward and AdamW update of Linear(D,hidden) -> ReLU -> Linear(hidden,n_out)
 //   replaces, per batch, dinov2salad/dinov2salad_finetuning.py:119-125 (preds = model(inputs); loss = MSELoss;
 //   zero_grad; backward; optimizer.step) with optimizer = torch.optim.AdamW(lr=1e-5) (:95) — for a FROZEN extractor whose
 //   descriptors were computed once (the reference re-runs the backbone every epoch; see finetune.py).
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void head_fwd_partial_kernel(
 // every output, po[wg][b][o] = sum over its 16 units of h * W2[o][unit] (DPP row sum: fixed tree); snap = W2 as it is BEFORE
 // this step's update (the update kernel reads the copy while designated workgroups rewrite the original).
 // The workgroup that arrives LAST at the counter (no spinning: the others have exited) adds the partial outputs in workgroup
-// order, + b2, and leaves diff[b][o] = output - target and the batch loss: the update kernel starts from diff instead of
+// order, + b2, and leaves diff[b][o] = output - target (Huber: half the clipped residual) and the batch loss: the update kernel starts from diff instead of
 // re-deriving the outputs in every workgroup (that serial chain of nwg2 loads cost 7 us of a 43 us step).
 // Hand-over: the partials go out as agent-scope (write-through) stores, vmcnt(0) = acknowledged, relaxed agent-scope
 // ticket, acquire fence in the last workgroup (the protocol of pose_fused_kernel).  The counter is zeroed by the forward
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void head_mid_kernel(
     const float* __restrict__ part, int nslice, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, const float* __restrict__ Y, long long y_stride, const int* __restrict__ idx,
     float* __restrict__ H, float* po, float* __restrict__ snap, float* __restrict__ diff, float* __restrict__ loss_out,
-    int* counter, int B, int hidden, int n_out) {
+    int* counter, int B, int hidden, int n_out, float huber_delta) {
   __shared__ float s_red[256];
   __shared__ int s_last;
   const int h0 = blockIdx.x * HT_H2, hl = threadIdx.x & 15, h = h0 + hl;
@@ -187,8 +187,14 @@ __global__ __launch_bounds__(256) void head_mid_kernel(
       const int b = t / n_out, oo = t - b * n_out;
       const long long row = idx ? (long long)idx[b] : (long long)b;
       const float d = (o + b2[oo]) - Y[row * y_stride + oo];
-      diff[t] = d;
-      sq = fmaf(d, d, sq);
+      if (huber_delta > 0.f) {       // nn.HuberLoss: 0.5 d^2 inside [-delta, delta], delta (|d| - 0.5 delta) outside; gradient d or +-delta.
+        const float ad = fabsf(d);   // `diff` carries HALF the gradient numerator: the update kernel scales by 2 / (B n_out) as for MSE
+        diff[t] = 0.5f * (ad < huber_delta ? d : copysignf(huber_delta, d));
+        sq += ad < huber_delta ? 0.5f * d * d : huber_delta * (ad - 0.5f * huber_delta);
+      } else {
+        diff[t] = d;
+        sq = fmaf(d, d, sq);
+      }
     }
   }
   __syncthreads();
@@ -423,10 +429,12 @@ extern "C" long long vpr_head_train_state_floats(int D, int hidden, int n_out) {
 static int head_train_step_impl(const float* X, long long x_stride, const int* idx, const float* Y, long long y_stride,
                                 int B, int D, int hidden, int n_out, float* W1, float* b1, float* W2, float* b2,
                                 float* m, float* v, int step, double lr, double beta1, double beta2, double eps,
-                                double weight_decay, float* loss_out, void* workspace, size_t workspace_bytes,
-                                hipStream_t stream) {
+                                double weight_decay, int loss_kind, double huber_delta, float* loss_out, void* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
   if (!X || !Y || !W1 || !b1 || !W2 || !b2 || !m || !v || !workspace || step < 1) return VPR_ERR_INVALID_ARG;
   if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !(weight_decay >= 0.0))
+    return VPR_ERR_INVALID_ARG;
+  if ((loss_kind != VPR_LOSS_MSE && loss_kind != VPR_LOSS_HUBER) || (loss_kind == VPR_LOSS_HUBER && !(huber_delta > 0.0)))
     return VPR_ERR_INVALID_ARG;
   HeadTrainPlan p;
   if (B < 1 || D < 1 || hidden < 1 || n_out < 1) return VPR_ERR_INVALID_ARG;
@@ -453,7 +461,7 @@ static int head_train_step_impl(const float* X, long long x_stride, const int* i
                                  X, x_stride, idx, (const float*)W1, part, B, D, hidden, sps, counter));
   VPR_TRY_LAUNCH(launch_kernel(head_mid_kernel, dim3(p.nwg2), dim3(256), 0, stream, (const float*)part, p.ks, (const float*)b1,
                                (const float*)W2, (const float*)b2, Y, y_stride, idx, H, po, snap, diff, loss_out, counter,
-                               B, hidden, n_out));
+                               B, hidden, n_out, loss_kind == VPR_LOSS_HUBER ? (float)huber_delta : 0.f));
   HeadTrainArgs a;
   a.X = X; a.x_stride = x_stride; a.idx = idx; a.Y = Y; a.y_stride = y_stride;
   a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.m = m; a.v = v;
@@ -483,17 +491,19 @@ static int head_train_step_impl(const float* X, long long x_stride, const int* i
 extern "C" int vpr_head_train_step(const float* X, long long x_stride, const int* idx, const float* Y, long long y_stride,
                                    int B, int D, int hidden, int n_out, float* W1, float* b1, float* W2, float* b2,
                                    float* m, float* v, int step, double lr, double beta1, double beta2, double eps,
-                                   double weight_decay, float* loss_out, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+                                   double weight_decay, int loss_kind, double huber_delta, float* loss_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   return head_train_step_impl(X, x_stride, idx, Y, y_stride, B, D, hidden, n_out, W1, b1, W2, b2, m, v, step, lr, beta1, beta2,
-                              eps, weight_decay, loss_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                              eps, weight_decay, loss_kind, huber_delta, loss_out, workspace, workspace_bytes,
+                              static_cast<hipStream_t>(stream));
 }
 
 extern "C" int vpr_head_train_epoch(const float* X, long long x_stride, const int* order, int n, int batch_size,
                                     const float* Y, long long y_stride, int D, int hidden, int n_out,
                                     float* W1, float* b1, float* W2, float* b2, float* m, float* v, int first_step,
                                     double lr, double beta1, double beta2, double eps, double weight_decay,
-                                    float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int loss_kind, double huber_delta, float* losses, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   if (!order || n < 1 || batch_size < 1 || first_step < 1) return VPR_ERR_INVALID_ARG;
   const int nb = (n + batch_size - 1) / batch_size;
   if ((long long)first_step + nb - 1 > 2147483647LL) return VPR_ERR_INVALID_ARG;
@@ -506,8 +516,9 @@ extern "C" int vpr_head_train_epoch(const float* X, long long x_stride, const in
     const int lo = i * batch_size;
     const int B = n - lo < batch_size ? n - lo : batch_size;
     VPR_TRY_LAUNCH(head_train_step_impl(X, x_stride, order + lo, Y, y_stride, B, D, hidden, n_out, W1, b1, W2, b2, m, v,
-                                        first_step + i, lr, beta1, beta2, eps, weight_decay, losses ? losses + i : nullptr,
-                                        workspace, workspace_bytes, static_cast<hipStream_t>(stream)));
+                                        first_step + i, lr, beta1, beta2, eps, weight_decay, loss_kind, huber_delta,
+                                        losses ? losses + i : nullptr, workspace, workspace_bytes,
+                                        static_cast<hipStream_t>(stream)));
   }
   return VPR_OK;
 }

@@ -60,14 +60,21 @@ def cache_descriptors_from_images(extractor: nn.Module, image_dir: str, filename
 def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, labels: np.ndarray,
                   epochs: int = 100, batch_size: int = 16, lr: float = 1e-5, save_dir: Optional[str] = None,
                   val: Optional[tuple] = None, seed: int = 0, log: Callable[[str], None] = print,
-                  engine: str = "auto") -> dict:
+                  engine: str = "auto", loss: str = "mse", huber_delta: float = 1.0, weight_decay: float = 1e-2,
+                  lr_schedule: Optional[Callable[[int, list], float]] = None) -> dict:
     """Trains model.regressor on cached descriptors.  labels [N,2] raw (lat, lon); they are
     standardised with a scaler fitted here (returned and, if save_dir, dumped as JSON).
     val = (val_descriptors, val_labels_raw) for the per-epoch de-normalised report.
     engine: "hip" (= "auto", the default) = vpr_head_train_epoch — needs the descriptors on the GPU and a Linear-ReLU-Linear head
     of a supported shape, and RAISES otherwise: there is no silent fallback; "torch" = the same loop as PyTorch autograd +
     torch.optim.AdamW, only when asked for by name (the CPU tests of the host logic, the A/B of scripts/head_train_bench.py).
-    Both engines draw the same batches (same seeded permutations) and write the same checkpoint format."""
+    Both engines draw the same batches (same seeded permutations) and write the same checkpoint format.
+    loss: "mse" (dinov2salad_finetuning.py:96) or "huber" with huber_delta (nn.HuberLoss(delta): dinov2salad_finetuning_2.py:154,
+    swin_attempt_2.py:158); weight_decay: AdamW's (:95 default 0.01; _2.py:153 passes it explicitly).
+    lr_schedule(epoch, history) -> lr for that epoch (host-side schedules such as the ReduceLROnPlateau of _2.py:155,236 are a
+    few lines of Python on the validation history; the learning rate is an argument of every training call)."""
+    if loss not in ("mse", "huber"):
+        raise ValueError(f"finetune_head: loss must be 'mse' or 'huber', got {loss!r}")
     dev = descriptors.device
     if engine not in ("auto", "hip", "torch"):
         raise ValueError(f"finetune_head: unknown engine {engine!r}")
@@ -81,9 +88,9 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
     head = model.regressor.to(dev).float()
     for p in head.parameters():
         p.requires_grad_(True)
-    opt = torch.optim.AdamW(head.parameters(), lr=lr)
-    loss_fn = nn.MSELoss()
-    hip = _HipHeadTrainer(head, descriptors.float().contiguous(), y, opt) if engine == "hip" else None
+    opt = torch.optim.AdamW(head.parameters(), lr=lr, weight_decay=weight_decay)
+    loss_fn = nn.MSELoss() if loss == "mse" else nn.HuberLoss(delta=huber_delta)
+    hip = _HipHeadTrainer(head, descriptors.float().contiguous(), y, opt, loss, huber_delta) if engine == "hip" else None
     g = torch.Generator(device="cpu").manual_seed(seed)
     n = descriptors.shape[0]
     history = []
@@ -93,6 +100,9 @@ def finetune_head(model: DINOv2RegressionModel, descriptors: torch.Tensor, label
             json.dump({"mean_": scaler.mean_.tolist(), "scale_": scaler.scale_.tolist()}, f)
     for epoch in range(epochs):
         head.train()
+        if lr_schedule is not None:
+            for grp in opt.param_groups:
+                grp["lr"] = float(lr_schedule(epoch, history))
         perm = torch.randperm(n, generator=g).to(dev)
         total, nb = 0.0, 0
         if engine == "hip":
@@ -142,7 +152,8 @@ class _HipHeadTrainer:
     kernels), AdamW moments live in two flat buffers ([W1 | b1 | W2 | b2]) and are copied into a torch.optim.AdamW's state
     only when a checkpoint wants `optimizer.state_dict()` (the reference's checkpoint dict, :130-135)."""
 
-    def __init__(self, head: nn.Module, X: torch.Tensor, Y: torch.Tensor, opt: torch.optim.Optimizer):
+    def __init__(self, head: nn.Module, X: torch.Tensor, Y: torch.Tensor, opt: torch.optim.Optimizer, loss: str = "mse",
+                 huber_delta: float = 1.0):
         from . import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.vpr.*)
         lin = [m for m in head if isinstance(m, nn.Linear)]
         rest = [m for m in head if not isinstance(m, (nn.Linear, nn.ReLU))]
@@ -155,9 +166,13 @@ class _HipHeadTrainer:
                 raise RuntimeError("finetune_head(engine='hip'): head parameters must be contiguous f32 GPU tensors")
         self.W1, self.b1, self.W2, self.b2 = (p.detach() for p in self.params)     # aliases that share the parameters' version counters
         self.m, self.v = ops.head_train_state(self.W1, self.W2)
-        grp = opt.param_groups[0]
-        self.hyper = dict(lr=grp["lr"], betas=tuple(grp["betas"]), eps=grp["eps"], weight_decay=grp["weight_decay"])
+        self.loss, self.huber_delta = loss, float(huber_delta)
         self.step = 0
+
+    @property
+    def hyper(self) -> dict:            # read at every pass: a schedule may have changed the optimizer's learning rate
+        grp = self.opt.param_groups[0]
+        return dict(lr=grp["lr"], betas=tuple(grp["betas"]), eps=grp["eps"], weight_decay=grp["weight_decay"])
 
     def epoch(self, perm: torch.Tensor, batch_size: int) -> torch.Tensor:
         """One pass in the order `perm` (a permutation of the cached rows, built by the caller; ragged last batch kept, as
@@ -166,7 +181,7 @@ class _HipHeadTrainer:
         h = self.hyper              # through the operator layer: the dispatcher sees the six in-place updates (version counters)
         losses = torch.ops.vpr.head_train_epoch(self.X, self.Y, perm32, batch_size, self.W1, self.b1, self.W2, self.b2, self.m,
                                                 self.v, self.step + 1, h["lr"], h["betas"][0], h["betas"][1], h["eps"],
-                                                h["weight_decay"])
+                                                h["weight_decay"], self.loss, self.huber_delta)
         self.step += losses.numel()
         return losses
 

@@ -652,6 +652,13 @@ def head_train_state_views(buf: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor
     return buf[:o1].view(hidden, D), buf[o1:o2], buf[o2:o3].view(n_out, hidden), buf[o3:o3 + n_out]
 
 
+def _loss_kind(loss: str) -> int:
+    """VPR_LOSS_MSE / VPR_LOSS_HUBER of include/vpr_amd.h."""
+    if loss not in ("mse", "huber"):
+        raise RuntimeError(f"head_train: loss must be 'mse' (nn.MSELoss) or 'huber' (nn.HuberLoss), got {loss!r}")
+    return 1 if loss == "huber" else 0
+
+
 def _head_train_check(X, Y, W1, b1, W2, b2, m, v):
     _need(X, torch.float32, "X", 2)
     _need(Y, torch.float32, "Y", 2)
@@ -673,7 +680,8 @@ def _head_train_check(X, Y, W1, b1, W2, b2, m, v):
 
 def head_train_epoch(X: torch.Tensor, Y: torch.Tensor, order: torch.Tensor, batch_size: int, W1: torch.Tensor, b1: torch.Tensor,
                      W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, first_step: int, lr: float = 1e-5,
-                     betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2) -> torch.Tensor:
+                     betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, loss: str = "mse",
+                     huber_delta: float = 1.0) -> torch.Tensor:
     """One pass over the rows listed in `order` (int32, device) in batches of `batch_size` (vpr_head_train_epoch: the whole
     launch sequence enqueued by ONE library call).  Returns the batch losses [ceil(n / batch_size)] (device tensor; nothing
     waits for the GPU).  The caller guarantees 0 <= order < X.shape[0]: the kernels gather rows by these indices unchecked."""
@@ -691,8 +699,8 @@ def head_train_epoch(X: torch.Tensor, Y: torch.Tensor, order: torch.Tensor, batc
     losses = torch.empty((n + batch_size - 1) // batch_size, dtype=torch.float32, device=X.device)
     st = L.vpr_head_train_epoch(_ptr(X), X.stride(0), _ptr(order), n, int(batch_size), _ptr(Y), Y.stride(0), D, hidden, n_out,
                                 _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(m), _ptr(v), int(first_step), float(lr),
-                                float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _ptr(losses),
-                                _ptr(ws), ws.numel(), _stream())
+                                float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _loss_kind(loss),
+                                float(huber_delta), _ptr(losses), _ptr(ws), ws.numel(), _stream())
     _lib.check(st, "vpr_head_train_epoch")
     for t in (W1, b1, W2, b2, m, v):
         torch.autograd.graph.increment_version(t)
@@ -702,11 +710,12 @@ def head_train_epoch(X: torch.Tensor, Y: torch.Tensor, order: torch.Tensor, batc
 def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor], W1: torch.Tensor, b1: torch.Tensor,
                     W2: torch.Tensor, b2: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-5,
                     betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                    loss_out: Optional[torch.Tensor] = None) -> None:
+                    loss_out: Optional[torch.Tensor] = None, loss: str = "mse", huber_delta: float = 1.0) -> None:
     """One batch of head-only fine-tuning on cached descriptors (vpr_head_train_step): forward, MSELoss, backward and
     AdamW update of Linear(D,hidden)-ReLU-Linear(hidden,n_out), in place on W1 / b1 / W2 / b2 / m / v.
     X [rows, D] f32, Y [rows, n_out] f32, idx [B] int32 (rows of the batch; None = all rows of X in order).  loss_out: a
-    one-element f32 tensor (e.g. losses[i:i+1]) that receives the batch loss.  No host synchronisation."""
+    one-element f32 tensor (e.g. losses[i:i+1]) that receives the batch loss.  loss: "mse" (nn.MSELoss) or "huber"
+    (nn.HuberLoss(delta=huber_delta)).  No host synchronisation."""
     D, hidden, n_out = _head_train_check(X, Y, W1, b1, W2, b2, m, v)
     if idx is not None:
         _need(idx, torch.int32, "idx", 1)
@@ -725,8 +734,8 @@ def head_train_step(X: torch.Tensor, Y: torch.Tensor, idx: Optional[torch.Tensor
     ws = workspace("head_train", nbytes, X.device)
     st = L.vpr_head_train_step(_ptr(X), X.stride(0), _ptr(idx), _ptr(Y), Y.stride(0), B, D, hidden, n_out,
                                _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(m), _ptr(v), int(step), float(lr),
-                               float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _ptr(loss_out),
-                               _ptr(ws), ws.numel(), _stream())
+                               float(betas[0]), float(betas[1]), float(eps), float(weight_decay), _loss_kind(loss),
+                               float(huber_delta), _ptr(loss_out), _ptr(ws), ws.numel(), _stream())
     _lib.check(st, "vpr_head_train_step")
     for t in (W1, b1, W2, b2, m, v):          # written behind PyTorch's back: version-keyed caches (pose-head weight planes) must see it
         torch.autograd.graph.increment_version(t)

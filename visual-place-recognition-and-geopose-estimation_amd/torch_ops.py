@@ -181,16 +181,17 @@ def _(x, gamma, beta, eps, Wh, bh, sincos_offset):
 @torch.library.custom_op("vpr::head_train_epoch", mutates_args=("W1", "b1", "W2", "b2", "m", "v"))
 def head_train_epoch(X: Tensor, Y: Tensor, order: Tensor, batch_size: int, W1: Tensor, b1: Tensor, W2: Tensor, b2: Tensor,
                      m: Tensor, v: Tensor, first_step: int, lr: float, beta1: float, beta2: float, eps: float,
-                     weight_decay: float) -> Tensor:
+                     weight_decay: float, loss: str = "mse", huber_delta: float = 1.0) -> Tensor:
     """One pass of head-only fine-tuning over the cached descriptor rows listed in `order` (int32), batches of `batch_size`:
-    forward, MSELoss, backward and AdamW of Linear(D,hidden)-ReLU-Linear(hidden,n_out) per batch, IN PLACE on the
+    forward, MSELoss (or HuberLoss), backward and AdamW of Linear(D,hidden)-ReLU-Linear(hidden,n_out) per batch, IN PLACE on the
     parameters and on the moment buffers (ops.head_train_state).  Returns the batch losses.  dinov2salad_finetuning.py:113-128
     (one epoch of the loop) on descriptors computed once.  vpr_head_train_epoch."""
-    return ops.head_train_epoch(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, (beta1, beta2), eps, weight_decay)
+    return ops.head_train_epoch(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, (beta1, beta2), eps, weight_decay,
+                                loss, huber_delta)
 
 
 @head_train_epoch.register_fake
-def _(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, beta1, beta2, eps, weight_decay):
+def _(X, Y, order, batch_size, W1, b1, W2, b2, m, v, first_step, lr, beta1, beta2, eps, weight_decay, loss="mse", huber_delta=1.0):
     return X.new_empty(((order.shape[0] + batch_size - 1) // batch_size,), dtype=torch.float32)
 
 
