@@ -258,3 +258,27 @@ def test_head_train_step_huber_loss_matches_oracle(D, hidden, n_out, N, bs, step
     assert rel.max() <= 2e-5 and worst <= 0.05 * lr * steps
     with pytest.raises(RuntimeError, match="mse.*huber|loss must be"):
         ops.head_train_step(X.to(DEV), Y.to(DEV), None, *params, m, v, 1, loss="l1")
+
+
+def test_finetune_head_huber_with_a_learning_rate_schedule_hip_equals_torch():
+    """finetune_head(loss="huber", weight_decay, lr_schedule): the HIP engine reads the optimizer's learning rate at every pass,
+    so a host-side schedule (ReduceLROnPlateau-style, dinov2salad_finetuning_2.py:155,236) steers both engines alike."""
+    N, epochs, bs, lr = 40, 3, 16, 2e-4
+    X, _ = _data(N, 8448, 2, 31)
+    rng = np.random.default_rng(5)
+    labels = np.stack([219658.0 + 900 * rng.standard_normal(N), 143506.0 + 1100 * rng.standard_normal(N)], 1)
+    Xg = X.to(DEV)
+    sched = lambda epoch, history: lr * (0.5 ** epoch)
+    runs = {}
+    for engine in ("hip", "torch"):
+        torch.manual_seed(2)
+        model = DINOv2RegressionModel(nn.Identity()).to(DEV)
+        out = finetune_head(model, Xg, labels, epochs=epochs, batch_size=bs, lr=lr, seed=4, log=lambda s: None, engine=engine,
+                            loss="huber", huber_delta=0.5, weight_decay=0.05, lr_schedule=sched)
+        runs[engine] = (model, out)
+        assert out["optimizer"].param_groups[0]["lr"] == lr * 0.25
+    steps = epochs * ((N + bs - 1) // bs)
+    for a, b in zip(runs["hip"][0].regressor.parameters(), runs["torch"][0].regressor.parameters()):
+        assert float((a - b).abs().max()) <= 0.05 * lr * steps
+    for ra, rb in zip(runs["hip"][1]["history"], runs["torch"][1]["history"]):
+        assert abs(ra["train_loss"] - rb["train_loss"]) <= 2e-5 * abs(rb["train_loss"])
