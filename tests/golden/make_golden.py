@@ -165,7 +165,69 @@ def swin_pool_head():
                         out=out.numpy(), out_unit=out_unit.numpy())
 
 
+def head_finetune():
+    """The reference's head-only training step, run HERE with the reference's own model class: DINOv2RegressionModel
+    (imported; same definition as dinov2salad_finetuning.py:21-37) around an identity extractor, `torch.optim.AdamW(
+    model.parameters(), lr=...)` and `nn.MSELoss()` as at :95-96, the loop body of :119-125, batches of 16 (:89) from a
+    seeded permutation, f32 as the reference runs it.  Stored: per-step losses and samples of the final parameters."""
+    mod = _load(os.path.join(REF, "dinov2salad/dinov2salad_validation.py"), "ref_dinov2salad_validation_ft",
+                ["icecream", "torchvision"])
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            return x
+
+    out = {"source": "DINOv2RegressionModel imported from dinov2salad/dinov2salad_validation.py:36-52 (= dinov2salad_finetuning.py:21-37); "
+                     "optimizer / loss / loop body as dinov2salad_finetuning.py:95-96,119-125; torch " + torch.__version__ + " CPU f32",
+           "weight_seed": 2468, "data_seed": 1357, "n": 64, "batch_size": 16, "epochs": 2,
+           "recipe": "torch.manual_seed(weight_seed); model as the reference builds it; g = Generator(data_seed); x = normalize(randn(n, 8448, g)); "
+                     "y = randn(n, 2, g); per epoch perm = randperm(n, g); batches perm[lo:lo+16]",
+           "runs": {}}
+    for name, lr in (("lr1e-5", 1e-5), ("lr1e-3", 1e-3)):
+        torch.manual_seed(out["weight_seed"])
+        model = mod.DINOv2RegressionModel(Stub())
+        g = torch.Generator().manual_seed(out["data_seed"])
+        x = torch.nn.functional.normalize(torch.randn(out["n"], 8448, generator=g), dim=1)
+        y = torch.randn(out["n"], 2, generator=g)
+        optimizer = torch.optim.AdamW(model.parameters(), lr=lr)
+        loss_fn = torch.nn.MSELoss()
+        model.train()
+        losses, orders = [], []
+        for epoch in range(out["epochs"]):
+            perm = torch.randperm(out["n"], generator=g)
+            orders.append(perm.tolist())
+            for lo in range(0, out["n"], out["batch_size"]):
+                idx = perm[lo:lo + out["batch_size"]]
+                preds = model(x[idx])
+                loss = loss_fn(preds, y[idx])
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                losses.append(float(loss.item()))
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        gi = torch.Generator().manual_seed(99)
+        w1_idx = torch.randint(0, 512 * 8448, (64,), generator=gi)
+        out["runs"][name] = {
+            "lr": lr, "losses": losses, "orders": orders,
+            "w1_sample_index": w1_idx.tolist(),
+            "w1_sample": sd["regressor.0.weight"].reshape(-1)[w1_idx].double().tolist(),
+            "b1_head": sd["regressor.0.bias"][:32].double().tolist(),
+            "w2": sd["regressor.2.weight"].double().tolist(),
+            "b2": sd["regressor.2.bias"].double().tolist(),
+            "w1_abs_mean": float(sd["regressor.0.weight"].double().abs().mean()),
+        }
+    torch.manual_seed(out["weight_seed"])
+    out["initial_sha256"] = {k: sha(v) for k, v in mod.DINOv2RegressionModel(Stub()).state_dict().items()}
+    with open(os.path.join(OUT, "head_finetune.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "head_finetune":     # only this fixture (the others are unchanged)
+        head_finetune()
+        print("head_finetune.json written to", OUT)
+        sys.exit(0)
+    head_finetune()
     head_dinov2salad()
     maae()
     scaler_and_csv_metrics()

@@ -282,3 +282,22 @@ def test_finetune_head_huber_with_a_learning_rate_schedule_hip_equals_torch():
         assert float((a - b).abs().max()) <= 0.05 * lr * steps
     for ra, rb in zip(runs["hip"][1]["history"], runs["torch"][1]["history"]):
         assert abs(ra["train_loss"] - rb["train_loss"]) <= 2e-5 * abs(rb["train_loss"])
+
+
+def test_head_train_reproduces_the_reference_training_run():
+    """vpr_head_train_epoch against tests/golden/head_finetune.json — losses and final weights of the reference's own model
+    class trained by its own optimizer / loss calls (generated by tests/golden/make_golden.py from the imported reference)."""
+    import json, os
+    from test_oracle_golden import check_finetune_against_golden, regen_finetune
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "head_finetune.json")))
+    reg, x, y = regen_finetune(meta)
+    for name, run in meta["runs"].items():
+        W = _gpu_params(reg)
+        m, v = ops.head_train_state(W[0], W[2])
+        step, losses = 1, []
+        for order in run["orders"]:
+            l = ops.head_train_epoch(x.to(DEV), y.to(DEV), torch.as_tensor(order, dtype=torch.int32, device=DEV), meta["batch_size"],
+                                     *W, m, v, step, lr=run["lr"])
+            step += l.numel()
+            losses += l.cpu().tolist()
+        check_finetune_against_golden(run, losses, *(w.cpu().numpy() for w in W), steps=len(losses))

@@ -41,6 +41,50 @@ def test_head_golden_matches_reference_class():
     assert (out - ref).abs().max().item() < 2e-6      # reference ran in fp32, oracle in fp64
 
 
+def regen_finetune(meta):
+    """Weights and data of tests/golden/head_finetune.json from its recipe (the weights are checked against the sha256 of the
+    reference-constructed model)."""
+    torch.manual_seed(meta["weight_seed"])
+    reg = nn.Sequential(nn.Linear(8448, 512), nn.ReLU(), nn.Linear(512, 2))
+    for k, v in reg.state_dict().items():
+        assert _sha(v) == meta["initial_sha256"]["regressor." + k], f"regenerated {k} differs from the reference-initialised weights"
+    g = torch.Generator().manual_seed(meta["data_seed"])
+    x = torch.nn.functional.normalize(torch.randn(meta["n"], 8448, generator=g), dim=1)
+    y = torch.randn(meta["n"], 2, generator=g)
+    return reg, x, y
+
+
+def check_finetune_against_golden(run, losses, W1, b1, W2, b2, steps):
+    """Losses and final parameters of a training run against the reference-generated fixture: the reference ran in f32, so
+    losses agree to 2e-5 relative and parameters to the AdamW bound 0.05 * lr * steps (tests/test_head_train_gpu.py)."""
+    ref_l = np.array(run["losses"])
+    assert np.abs(np.asarray(losses, dtype=np.float64) - ref_l).max() <= 2e-5 * np.abs(ref_l).max()
+    tol = 0.05 * run["lr"] * steps
+    W1 = np.asarray(W1, dtype=np.float64).reshape(-1)
+    assert np.abs(W1[np.array(run["w1_sample_index"])] - np.array(run["w1_sample"])).max() <= tol
+    assert np.abs(np.asarray(b1, dtype=np.float64)[:32] - np.array(run["b1_head"])).max() <= tol
+    assert np.abs(np.asarray(W2, dtype=np.float64) - np.array(run["w2"])).max() <= tol
+    assert np.abs(np.asarray(b2, dtype=np.float64) - np.array(run["b2"])).max() <= tol
+    assert abs(np.abs(W1).mean() - run["w1_abs_mean"]) <= tol
+
+
+def test_finetune_oracle_reproduces_the_reference_training_run():
+    """oracle/finetune.py against tests/golden/head_finetune.json: the reference's DINOv2RegressionModel trained with its own
+    optimizer / loss calls (tests/golden/make_golden.py head_finetune), 8 steps at lr 1e-5 (the script's) and 1e-3."""
+    from oracle import finetune as oft
+    meta = json.load(open(os.path.join(G, "head_finetune.json")))
+    reg, x, y = regen_finetune(meta)
+    for name, run in meta["runs"].items():
+        st = oft.HeadState(*(p.detach().numpy() for p in (reg[0].weight, reg[0].bias, reg[2].weight, reg[2].bias)))
+        losses = []
+        for order in run["orders"]:
+            order = np.array(order)
+            for lo in range(0, meta["n"], meta["batch_size"]):
+                idx = order[lo:lo + meta["batch_size"]]
+                losses.append(oft.train_step(st, x.numpy()[idx], y.numpy()[idx], lr=run["lr"]))
+        check_finetune_against_golden(run, losses, *st.p, steps=len(losses))
+
+
 def test_maae_golden():
     d = json.load(open(os.path.join(G, "maae.json")))
     from vpr_amd import postproc
