@@ -173,7 +173,18 @@ def head_train_row(dev, hbm) -> dict:
 
     ms_t = _avg_ms(torch_epoch, n=5, warm=1) / 16
     by = 7 * hidden * D * 4 + 2 * Bt * D * 4
-    return dict(entry="vpr_head_train_epoch (per batch: forward, MSELoss, backward, AdamW — three launches)",
+    traffic, tsrc = None, None
+    try:                                                        # PMC traffic per step, only if measured on this kernel source
+        import hashlib
+        with open(os.path.join(ROOT, "profiles", "r03_head_train_pmc.json")) as f:
+            pj = json.load(f)
+        with open(os.path.join(ROOT, pj["source"]), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest()[:16] == pj["source_sha16"]:
+                traffic, tsrc = pj["hbm_bytes_per_step"], f"profiles/r03_head_train_pmc.json (source_sha16 {pj['source_sha16']})"
+    except Exception:                                           # noqa: BLE001
+        pass
+    return dict(entry="vpr_head_train_epoch (per batch: forward, MSELoss, backward, AdamW — three launches)", traffic=traffic,
+                traffic_source=tsrc,
                 shape=f"B={Bt} D={D} hidden={hidden} n_out={n_out} f32", torch_autograd_adamw_ms=ms_t, speedup_vs_torch=ms_t / ms,
                 **hbm(by, ms))
 
