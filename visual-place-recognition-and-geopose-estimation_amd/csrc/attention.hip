@@ -146,8 +146,13 @@ __device__ __forceinline__ float attn_phase2(const AttnCtx& cx, const bf16x8 (&p
 template <int NW, bool PIPE, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int T, int Tp, long long tail_row0, int H,
-    float scale_log2e) {
+    float scale_log2e, int dephase) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // A/B (VPR_ATTN_VARIANT = 20 + n): the workgroups that fill the SECOND slot of every CU in the first wave of the grid
+  // (256 <= blockIdx < 512 on 256 CUs) start n * ~1 us late, so that the two workgroups of a CU stop running their
+  // staging / compute phases in lockstep
+  if (dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(33);       // 33 * 64 clocks ~ 1 us
   char* Ks = smem;                                                   // [AT_KP][64] bf16, swizzled 128-B rows
   char* Vs = smem + AT_KP * 128;                                     // [AT_KP][64] bf16, same layout
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -264,13 +269,14 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
   if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) return VPR_ERR_UNSUPPORTED;
   const int variant = tune_or(TUNE_ATTN_VARIANT, 0);      // A/B switch; 0 = default
   const float c = scale * 1.4426950408889634f;
+  const int dephase = (variant >= 20 && variant <= 60) ? variant - 20 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define VPR_ATTN_LAUNCH(NW, PIPE)                                                                        \
   do {                                                                                                   \
     static PerDeviceFlag attr = {};                                                                      \
     VPR_TRY_LAUNCH(optin_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<NW, PIPE>), AT_LDS, attr)); \
     VPR_TRY_LAUNCH(launch_kernel(attention_kernel<NW, PIPE>, dim3((unsigned)(B * H)), dim3(NW * 64), AT_LDS, st, \
-                                 qkv, out, T, Tp, tail_row0, H, c));                                                    \
+                                 qkv, out, T, Tp, tail_row0, H, c, dephase));                                           \
   } while (0)
 #define VPR_ATTN_ABL(A)                                                                                   \
   do {                                                                                                   \
@@ -278,7 +284,7 @@ static int attention_launch(const uint16_t* qkv, uint16_t* out, int B, int T, in
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_LDS) != hipSuccess)      \
       return VPR_ERR_LAUNCH;                                                                             \
     VPR_TRY_LAUNCH(launch_kernel(attention_kernel<8, false, A>, dim3((unsigned)(B * H)), dim3(512), AT_LDS, st, \
-                                 qkv, out, T, Tp, tail_row0, H, c));                                     \
+                                 qkv, out, T, Tp, tail_row0, H, c, 0));                                  \
   } while (0)
   // Ablations (variants 12-14, timing only): K/V + Q staging alone 11.4 us (101 MB of qkv at ~9 TB/s out of the
   // Infinity Cache), + QK^T 24.2, + softmax 32.9, full kernel 37.5 us: the phases add up, i.e. the two workgroups of a
